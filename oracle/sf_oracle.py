@@ -1,0 +1,400 @@
+"""
+CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A numpy/scipy restatement of the Starfish per-MCMC-step log-likelihood path, written from the
+mathematics of the reference (file:line citations are relative to /root/reference).  It is the
+checker for the HIP path, never the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; ``starfish_amd`` never does.
+
+Pinning: every function below is checked against outputs of the real reference (imported in the
+authoring container by ``tools/gen_golden.py``) through the fixtures committed under
+``tests/golden/`` (``tests/test_oracle_golden.py``).  The reference's own tests hold no numeric
+known-answer vectors for this path, so those generated fixtures are the pin.
+
+Third-party arithmetic the reference delegates to and that is therefore used here as well (same
+pinned dependency, ``scipy>=1.3`` / ``numpy>=1.16`` in the reference's setup.py:49-51):
+LAPACK dpotrf/dpotrs/dgesv, pocketfft rfft/irfft, FITPACK curfit/splev, cephes j1.
+An independent B-spline collocation restatement of the FITPACK k=5 interpolating spline
+(``quintic_collocation_*``) is included because that is the algorithm the HIP kernels implement.
+"""
+
+from math import pi
+
+import numpy as np
+from numpy.polynomial.chebyshev import chebval
+from scipy.interpolate import InterpolatedUnivariateSpline
+from scipy.linalg import cho_factor, cho_solve
+from scipy.special import j1
+
+C_KMS = 2.99792458e5  # Starfish/constants.py:7
+JITTER = 1e-10  # Starfish/models/spectrum_model.py:399
+
+
+# --------------------------------------------------------------------------- grids / velocity
+def min_velocity_step(wave):
+    """Starfish/utils.py:8-22 -- c * min(dlam / lam)."""
+    wave = np.asarray(wave, dtype=np.float64)
+    return C_KMS * np.min(np.diff(wave) / wave[:-1])
+
+
+def log_lambda_grid(dv, start, end):
+    """Starfish/utils.py:44-88 -- power-of-two log-lambda grid with spacing <= dv."""
+    if start >= end:
+        raise ValueError("Wavelength must be increasing, but start >= end")
+    if start <= 0 or end <= 0:
+        raise ValueError("Cannot have negative or 0 wavelength")
+    step = np.log10(dv / C_KMS + 1.0)
+    lo = np.log10(start)
+    hi = np.log10(end)
+    want = (hi - lo) / step
+    n = 2
+    while n < want:
+        n *= 2
+    cdelt = (hi - lo) / (n - 1)
+    return 10 ** (lo + cdelt * np.arange(n)), lo, cdelt
+
+
+# --------------------------------------------------------------------------- covariance kernels
+def matern32_global(wave, amplitude, lengthscale):
+    """Starfish/models/kernels.py:7-41 -- Hann-tapered Matern-3/2 in velocity distance."""
+    w = np.asarray(wave, dtype=np.float64)
+    wi = w[None, :]
+    wj = w[:, None]
+    r = C_KMS / 2 * np.abs((wi - wj) / (wi + wj))
+    r0 = 6 * lengthscale
+    inside = r <= r0
+    rr = np.where(inside, r, 0.0)
+    taper = 0.5 + 0.5 * np.cos(pi * rr / r0)
+    body = taper * amplitude * (1 + np.sqrt(3) * rr / lengthscale) * np.exp(
+        -np.sqrt(3) * rr / lengthscale
+    )
+    return np.where(inside, body, 0.0)
+
+
+def gaussian_local(wave, amplitude, mu, sigma):
+    """Starfish/models/kernels.py:44-81 -- Hann-tapered Gaussian patch centred on mu."""
+    w = np.asarray(wave, dtype=np.float64)
+    d = C_KMS / mu * np.abs(w - mu)
+    di = d[None, :]
+    dj = d[:, None]
+    r_tap = np.maximum(di, dj)
+    r2 = di**2 + dj**2
+    r0 = 4 * sigma
+    inside = r_tap <= r0
+    rt = np.where(inside, r_tap, 0.0)
+    taper = 0.5 + 0.5 * np.cos(pi * rt / r0)
+    body = taper * amplitude * np.exp(-0.5 * np.where(inside, r2, 0.0) / sigma**2)
+    return np.where(inside, body, 0.0)
+
+
+# --------------------------------------------------------------------------- transforms
+def rot_broaden(wave, flux, vsini):
+    """Starfish/transforms.py:93-134 -- Gray rotational kernel applied in Fourier space."""
+    if vsini <= 0:
+        raise ValueError("vsini must be positive")
+    flux = np.asarray(flux, dtype=np.float64)
+    n = flux.shape[-1]
+    dv = min_velocity_step(wave)
+    freq = np.fft.rfftfreq(n, dv)
+    spec = np.fft.rfft(flux)
+    u = (2.0 * pi * vsini * freq)[1:]
+    sb = j1(u) / u - 3 * np.cos(u) / (2 * u**2) + 3.0 * np.sin(u) / (2 * u**3)
+    spec *= np.concatenate(([1.0], sb))
+    return np.fft.irfft(spec, n=n)
+
+
+def inst_broaden(wave, flux, fwhm):
+    """Starfish/transforms.py:45-90 -- Gaussian instrumental profile in Fourier space."""
+    if fwhm < 0:
+        raise ValueError("FWHM must be non-negative")
+    flux = np.asarray(flux, dtype=np.float64)
+    n = flux.shape[-1]
+    dv = min_velocity_step(wave)
+    freq = np.fft.rfftfreq(n, d=dv)
+    spec = np.fft.rfft(flux)
+    sigma = fwhm / 2.355
+    spec *= np.exp(-2 * (pi * sigma * freq) ** 2)
+    return np.fft.irfft(spec, n=n)
+
+
+def doppler(wave, vz):
+    """Starfish/transforms.py:137-158."""
+    return np.asarray(wave) * np.sqrt((C_KMS + vz) / (C_KMS - vz))
+
+
+def quintic_resample(wave, flux, new_wave):
+    """Starfish/transforms.py:11-42 -- FITPACK interpolating k=5 spline per row."""
+    new_wave = np.asarray(new_wave, dtype=np.float64)
+    if np.any(new_wave <= 0):
+        raise ValueError("Wavelengths must be positive")
+    flux = np.asarray(flux, dtype=np.float64)
+    if flux.ndim > 1:
+        return np.array(
+            [InterpolatedUnivariateSpline(wave, row, k=5)(new_wave) for row in flux]
+        )
+    return InterpolatedUnivariateSpline(wave, flux, k=5)(new_wave)
+
+
+def cheb_correct(wave, flux, coeffs):
+    """Starfish/transforms.py:271-304 -- multiply by a Chebyshev series in lam/lam_max."""
+    coeffs = np.asarray(coeffs)
+    if coeffs.ndim == 1 and coeffs[0] != 1:
+        raise ValueError(
+            "For single spectrum the linear Chebyshev coefficient (c[0]) must be 1"
+        )
+    wave = np.asarray(wave, dtype=np.float64)
+    return flux * chebval(wave / wave.max(), coeffs, tensor=False)
+
+
+def trapezoid(y, x):
+    """numpy.trapz as called from Starfish/transforms.py:265-268."""
+    y = np.asarray(y, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    return (np.diff(x) * (y[..., 1:] + y[..., :-1]) / 2.0).sum(axis=-1)
+
+
+def renorm_factor(wave, flux, reference_flux):
+    """Starfish/transforms.py:265-268."""
+    return trapezoid(reference_flux, wave) / trapezoid(flux, wave)
+
+
+# ------------------------------------------------- B-spline collocation restatement of FITPACK k=5
+def quintic_knots(x):
+    """Knot vector FITPACK's curfit uses for an interpolating (s=0) k=5 spline:
+    x[0] six times, x[3:-3], x[-1] six times (fpcurf.f, 'iopt=0, s=0' branch)."""
+    x = np.asarray(x, dtype=np.float64)
+    return np.concatenate((np.repeat(x[0], 6), x[3:-3], np.repeat(x[-1], 6)))
+
+
+def bspline_basis6(t, ell, x):
+    """The six degree-5 B-splines that are non-zero on [t[ell], t[ell+1]) evaluated at x,
+    by the Cox-de Boor recurrence exactly as FITPACK's fpbspl.f orders it.
+    Returns h[0..5] multiplying coefficients c[ell-5 .. ell]."""
+    h = np.zeros(6)
+    hh = np.zeros(5)
+    h[0] = 1.0
+    for j in range(1, 6):
+        hh[:j] = h[:j]
+        h[0] = 0.0
+        for i in range(1, j + 1):
+            li = ell + i
+            lj = li - j
+            f = hh[i - 1] / (t[li] - t[lj])
+            h[i - 1] = h[i - 1] + f * (t[li] - x)
+            h[i] = f * (x - t[lj])
+    return h
+
+
+def find_interval(t, n_coef, x):
+    """splev.f: largest ell with t[ell] <= x, clamped to [5, n_coef-1] (0-based)."""
+    ell = int(np.searchsorted(t, x, side="right")) - 1
+    return min(max(ell, 5), n_coef - 1)
+
+
+def quintic_collocation_band(x):
+    """Banded collocation matrix A[i, j] = B_j(x_i) for the interpolation problem.
+    Returns (ab, offs): ab[i, :] holds A[i, offs[i] : offs[i]+6]."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    t = quintic_knots(x)
+    ab = np.zeros((n, 6))
+    offs = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        ell = find_interval(t, n, x[i])
+        ab[i] = bspline_basis6(t, ell, x[i])
+        offs[i] = ell - 5
+    return ab, offs, t
+
+
+def quintic_collocation_fit(x, y):
+    """Dense-solve version of the interpolation conditions (small n only; test helper)."""
+    ab, offs, t = quintic_collocation_band(x)
+    n = len(x)
+    A = np.zeros((n, n))
+    for i in range(n):
+        A[i, offs[i] : offs[i] + 6] = ab[i]
+    return np.linalg.solve(A, np.asarray(y, dtype=np.float64)), t
+
+
+def quintic_collocation_eval(t, c, xq):
+    out = np.empty(len(xq))
+    n = len(c)
+    for q, x in enumerate(xq):
+        ell = find_interval(t, n, x)
+        out[q] = bspline_basis6(t, ell, x) @ c[ell - 5 : ell + 1]
+    return out
+
+
+# --------------------------------------------------------------------------- emulator (query side)
+def rbf_block(X, Z, variance, lengthscale):
+    """Starfish/emulator/kernels.py:5-26 -- sigma^2 exp(-1/2 |(x-z)/l|^2)."""
+    X = np.atleast_2d(X) / lengthscale
+    Z = np.atleast_2d(Z) / lengthscale
+    d2 = ((X[:, None, :] - Z[None, :, :]) ** 2).sum(-1)
+    return variance * np.exp(-0.5 * d2)
+
+
+def rbf_blockdiag(X, Z, variances, lengthscales):
+    """Starfish/emulator/kernels.py:29-49 -- block-diagonal stack, one RBF block per component."""
+    blocks = [rbf_block(X, Z, v, l) for v, l in zip(variances, lengthscales)]
+    rows = sum(b.shape[0] for b in blocks)
+    cols = sum(b.shape[1] for b in blocks)
+    out = np.zeros((rows, cols))
+    r = c = 0
+    for b in blocks:
+        out[r : r + b.shape[0], c : c + b.shape[1]] = b
+        r += b.shape[0]
+        c += b.shape[1]
+    return out
+
+
+def phi_squared(eigenspectra, M):
+    """Starfish/emulator/_utils.py:28-48 -- Phi^T Phi = (E E^T) kron I_M (component-major)."""
+    E = np.asarray(eigenspectra, dtype=np.float64)
+    dots = E @ E.T
+    return np.kron(dots, np.eye(M))
+
+
+def w_hat_estimate(eigenspectra, fluxes):
+    """Starfish/emulator/_utils.py:10-25 -- least-squares PCA weights, component-major."""
+    E = np.asarray(eigenspectra, dtype=np.float64)
+    F = np.asarray(fluxes, dtype=np.float64)
+    M = len(F)
+    rhs = (E @ F.T).reshape(-1)
+    fac = cho_factor(phi_squared(E, M))
+    return cho_solve(fac, rhs)
+
+
+def emulator_v11(eigenspectra, grid_points, variances, lengthscales, lambda_xi=1.0):
+    """Starfish/emulator/emulator.py:123-128."""
+    M = len(grid_points)
+    return np.linalg.inv(phi_squared(eigenspectra, M)) / lambda_xi + rbf_blockdiag(
+        grid_points, grid_points, variances, lengthscales
+    )
+
+
+def default_lengthscales(grid_points, ncomps):
+    """Starfish/emulator/emulator.py:109-116 -- 3 x the largest grid step per axis."""
+    g = np.asarray(grid_points, dtype=np.float64)
+    sep = np.array([np.diff(np.unique(col)).max() for col in g.T])
+    return np.tile(3 * sep, (ncomps, 1))
+
+
+def emulator_query(grid_points, params, variances, lengthscales, v11, w_hat):
+    """Starfish/emulator/emulator.py:330-394 -- GP conditional mean / covariance of the weights."""
+    params = np.atleast_2d(params)
+    g = np.asarray(grid_points, dtype=np.float64)
+    if np.any(params < g.min(axis=0)) or np.any(params > g.max(axis=0)):
+        raise ValueError("Querying emulator outside of original parameter range.")
+    v12 = rbf_blockdiag(g, params, variances, lengthscales)
+    v22 = rbf_blockdiag(params, params, variances, lengthscales)
+    mu = v12.T @ np.linalg.solve(v11, w_hat)
+    cov = v22 - v12.T @ np.linalg.solve(v11, v12)
+    return mu, cov
+
+
+# --------------------------------------------------------------------------- the model
+class OracleOrder:
+    """Static per-order state mirroring SpectrumModel.__init__
+    (Starfish/models/spectrum_model.py:126-181) for a single order."""
+
+    def __init__(
+        self,
+        wave,
+        flux,
+        sigma,
+        emu_wl,
+        eigenspectra,
+        flux_mean,
+        flux_std,
+        grid_points,
+        w_hat,
+        variances=None,
+        lengthscales=None,
+        lambda_xi=1.0,
+    ):
+        self.wave = np.asarray(wave, dtype=np.float64)
+        self.flux = np.asarray(flux, dtype=np.float64)
+        self.sigma = np.asarray(sigma, dtype=np.float64)
+        self.emu_wl = np.asarray(emu_wl, dtype=np.float64)
+        self.eigenspectra = np.asarray(eigenspectra, dtype=np.float64)
+        self.m = self.eigenspectra.shape[0]
+        self.grid_points = np.asarray(grid_points, dtype=np.float64)
+        self.w_hat = np.asarray(w_hat, dtype=np.float64)
+        self.variances = (
+            np.asarray(variances, dtype=np.float64)
+            if variances is not None
+            else 1e4 * np.ones(self.m)
+        )
+        self.lengthscales = (
+            np.asarray(lengthscales, dtype=np.float64)
+            if lengthscales is not None
+            else default_lengthscales(self.grid_points, self.m)
+        )
+        self.v11 = emulator_v11(
+            self.eigenspectra, self.grid_points, self.variances, self.lengthscales, lambda_xi
+        )
+        bulk = np.vstack([self.eigenspectra, flux_mean, flux_std])  # emulator.py:396-402
+        dv = min_velocity_step(self.wave)
+        self.min_dv_wave, _, _ = log_lambda_grid(dv, self.emu_wl.min(), self.emu_wl.max())
+        self.bulk_fluxes = quintic_resample(self.emu_wl, bulk, self.min_dv_wave)
+
+
+def forward_model(order, p):
+    """Steps 1-10 of SURVEY.md section 0 == SpectrumModel.__call__
+    (Starfish/models/spectrum_model.py:277-365).
+
+    ``p`` is a plain dict: optional vsini, vz, cheb (c1..), log_scale, norm (float factor),
+    global_cov=(log_amp, log_ls), local_cov=[(mu, log_amp, log_sigma), ...], grid=[...].
+    Returns flux (N,), cov (N, N) and the scale factor used."""
+    wave = order.min_dv_wave
+    rows = order.bulk_fluxes
+    if "vsini" in p:
+        rows = rot_broaden(wave, rows, p["vsini"])
+    if "vz" in p:
+        wave = doppler(wave, p["vz"])
+    rows = quintic_resample(wave, rows, order.wave)
+    if "cheb" in p:
+        rows = cheb_correct(order.wave, rows, [1, *p["cheb"]])
+    w_mu, w_cov = emulator_query(
+        order.grid_points, p["grid"], order.variances, order.lengthscales, order.v11, order.w_hat
+    )
+    eig, mean, std = rows[:-2], rows[-2], rows[-1]
+    X = eig * std
+    flux = w_mu @ X + mean
+    norm = p.get("norm", 1)
+    if "log_scale" in p:
+        scale = np.exp(p["log_scale"]) * norm
+    else:
+        scale = renorm_factor(order.wave, flux * norm, order.flux) * norm
+    flux = flux * scale
+    X = X * scale
+    fac = cho_factor(w_cov)
+    cov = X.T @ cho_solve(fac, X)
+    idx = np.arange(len(order.wave))
+    cov[idx, idx] += order.sigma**2
+    if "global_cov" in p:
+        la, ll = p["global_cov"]
+        cov += matern32_global(order.wave, np.exp(la), np.exp(ll))
+    if p.get("local_cov"):
+        loc = 0
+        for mu, la, ls in p["local_cov"]:
+            loc = loc + gaussian_local(order.wave, np.exp(la), mu, np.exp(ls))
+        cov += loc
+    return flux, cov, scale
+
+
+def log_likelihood(order, p, return_parts=False):
+    """SpectrumModel.log_likelihood without priors
+    (Starfish/models/spectrum_model.py:397-405): -(logdet + R^T C^-1 R) / 2."""
+    flux, cov, _ = forward_model(order, p)
+    idx = np.arange(len(flux))
+    cov[idx, idx] += JITTER
+    fac = cho_factor(cov, overwrite_a=True)
+    logdet = 2 * np.sum(np.log(fac[0].diagonal()))
+    R = flux - order.flux
+    sqmah = R @ cho_solve(fac, R)
+    lnl = -(logdet + sqmah) / 2
+    if return_parts:
+        return lnl, logdet, sqmah, R
+    return lnl

@@ -1,0 +1,150 @@
+"""
+Synthetic single-order problems: plain numpy arrays only, so the same
+inputs can be handed to the HIP path, to the CPU oracle and -- in the authoring container -- to the
+real reference (tools/gen_golden.py).  All randomness is ``np.random.default_rng(seed)``.
+"""
+
+from itertools import product
+
+import numpy as np
+
+C_KMS = 2.99792458e5
+
+
+def _log_grid(dv, start, end):
+    step = np.log10(dv / C_KMS + 1.0)
+    lo, hi = np.log10(start), np.log10(end)
+    n = 2
+    while n < (hi - lo) / step:
+        n *= 2
+    return 10 ** (lo + (hi - lo) / (n - 1) * np.arange(n))
+
+
+def make_order(N=4096, m=8, seed=0, dv=2.0, wave0=5000.0, pad=20.0):
+    """One echelle order of N pixels and a matching m-component emulator over a 3x3x3 grid."""
+    rng = np.random.default_rng(seed)
+    wave = wave0 * np.exp(np.arange(N) * dv / C_KMS)
+    emu_wl = _log_grid(dv, wave.min() - pad, wave.max() + pad)
+    nf = len(emu_wl)
+    q, _ = np.linalg.qr(rng.standard_normal((nf, m)))
+    eig = np.ascontiguousarray(q.T)
+    flux_mean = 1 + 0.1 * np.sin(emu_wl / 7)
+    flux_std = 0.05 + 0.01 * np.cos(emu_wl / 3)
+    grid = np.array(
+        list(product((6000.0, 6100.0, 6200.0), (4.0, 4.5, 5.0), (-1.0, -0.5, 0.0)))
+    )
+    M = len(grid)
+    weights = rng.standard_normal((M, m))
+    fluxes = weights @ eig
+    # least-squares PCA weights, component-major (i*M + j)
+    dots = eig @ eig.T
+    rhs = (eig @ fluxes.T).reshape(-1)
+    w_hat = np.linalg.solve(np.kron(dots, np.eye(M)), rhs)
+    data_flux = 1 + 0.1 * np.sin(wave / 7) + 0.01 * rng.standard_normal(N)
+    sigma = 0.01 * np.ones(N)
+    return dict(
+        wave=wave,
+        flux=data_flux,
+        sigma=sigma,
+        emu_wl=emu_wl,
+        eigenspectra=eig,
+        flux_mean=flux_mean,
+        flux_std=flux_std,
+        grid_points=grid,
+        param_names=["T", "logg", "Z"],
+        weights=weights,
+        w_hat=w_hat,
+        factors=np.ones(M),
+    )
+
+
+def centre_params(order):
+    """The centre of the walker ball."""
+    wave = order["wave"]
+    N = len(wave)
+    return dict(
+        vz=10.0,
+        vsini=30.0,
+        log_scale=0.0,
+        global_cov=dict(log_amp=-9.0, log_ls=float(np.log(10.0))),
+        local_cov=[
+            dict(mu=float(wave[N // 3]), log_amp=-8.0, log_sigma=float(np.log(15.0)))
+        ],
+        cheb=[0.01, -0.02],
+        grid_params=[6050.0, 4.2, -0.3],
+    )
+
+
+# label order produced by SpectrumModel for centre_params (kwargs order, cheb last, then grid)
+LABELS = (
+    "vz",
+    "vsini",
+    "log_scale",
+    "global_cov:log_amp",
+    "global_cov:log_ls",
+    "local_cov:0:mu",
+    "local_cov:0:log_amp",
+    "local_cov:0:log_sigma",
+    "cheb:1",
+    "cheb:2",
+    "T",
+    "logg",
+    "Z",
+)
+
+_BALL = {
+    "vz": 0.1,
+    "vsini": 0.1,
+    "log_scale": 0.01,
+    "global_cov:log_amp": 0.05,
+    "global_cov:log_ls": 0.05,
+    "local_cov:0:mu": 0.01,
+    "local_cov:0:log_amp": 0.05,
+    "local_cov:0:log_sigma": 0.05,
+    "cheb:1": 1e-3,
+    "cheb:2": 1e-3,
+    "T": 1.0,
+    "logg": 0.01,
+    "Z": 0.01,
+}
+
+
+def centre_vector(order):
+    c = centre_params(order)
+    return np.array(
+        [
+            c["vz"],
+            c["vsini"],
+            c["log_scale"],
+            c["global_cov"]["log_amp"],
+            c["global_cov"]["log_ls"],
+            c["local_cov"][0]["mu"],
+            c["local_cov"][0]["log_amp"],
+            c["local_cov"][0]["log_sigma"],
+            c["cheb"][0],
+            c["cheb"][1],
+            *c["grid_params"],
+        ]
+    )
+
+
+def walker_ball(order, B=128, seed=1):
+    """B parameter vectors (B, 13) in LABELS order scattered around the centre."""
+    rng = np.random.default_rng(seed)
+    p0 = centre_vector(order)
+    scales = np.array([_BALL[k] for k in LABELS])
+    return p0[None, :] + scales[None, :] * rng.standard_normal((B, len(LABELS)))
+
+
+def vector_to_oracle_params(vec):
+    """LABELS-ordered vector -> the dict understood by oracle.sf_oracle.forward_model."""
+    v = dict(zip(LABELS, vec))
+    return dict(
+        vz=v["vz"],
+        vsini=v["vsini"],
+        log_scale=v["log_scale"],
+        global_cov=(v["global_cov:log_amp"], v["global_cov:log_ls"]),
+        local_cov=[(v["local_cov:0:mu"], v["local_cov:0:log_amp"], v["local_cov:0:log_sigma"])],
+        cheb=[v["cheb:1"], v["cheb:2"]],
+        grid=[v["T"], v["logg"], v["Z"]],
+    )

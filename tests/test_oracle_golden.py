@@ -1,0 +1,132 @@
+"""Pin the CPU oracle (oracle/sf_oracle.py) to vectors produced by the real reference
+(tools/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import sf_oracle as O
+from starfish_amd import synth
+from conftest import load_golden
+
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+
+
+def oracle_order(o, **kw):
+    return O.OracleOrder(
+        o["wave"], o["flux"], o["sigma"], o["emu_wl"], o["eigenspectra"], o["flux_mean"],
+        o["flux_std"], o["grid_points"], o["w_hat"], **kw
+    )
+
+
+@pytest.mark.parametrize("N", [64, 200])
+def test_kernels_match_reference(N):
+    g = load_golden("kernels.npz")
+    wave = g[f"wave_{N}"]
+    for i, (a, l) in enumerate(g[f"g_params_{N}"]):
+        np.testing.assert_allclose(O.matern32_global(wave, a, l), g[f"g_{N}_{i}"], rtol=1e-15, atol=0)
+    for i, (a, mu, s) in enumerate(g[f"l_params_{N}"]):
+        np.testing.assert_allclose(O.gaussian_local(wave, a, mu, s), g[f"l_{N}_{i}"], rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["s", "l"])
+def test_transforms_match_reference(tag):
+    g = load_golden("transforms.npz")
+    grid, wave, flux = g[f"{tag}_grid"], g[f"{tag}_wave"], g[f"{tag}_flux"]
+    for i, v in enumerate(g[f"{tag}_vsini"]):
+        np.testing.assert_allclose(O.rot_broaden(grid, flux, v), g[f"{tag}_rot_{i}"], rtol=0, atol=1e-15)
+    for i, f in enumerate(g[f"{tag}_fwhm"]):
+        np.testing.assert_allclose(O.inst_broaden(grid, flux, f), g[f"{tag}_inst_{i}"], rtol=0, atol=1e-15)
+    for i, vz in enumerate(g[f"{tag}_vz"]):
+        sh = O.doppler(grid, vz)
+        np.testing.assert_array_equal(sh, g[f"{tag}_dop_{i}"])
+        np.testing.assert_allclose(O.quintic_resample(sh, flux, g[f"{tag}_resq_{i}"]), g[f"{tag}_res_{i}"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(O.cheb_correct(wave, g[f"{tag}_cheb_in"], g[f"{tag}_cheb_c"]), g[f"{tag}_cheb"], rtol=1e-15)
+    res0 = g[f"{tag}_cheb_in"]
+    np.testing.assert_allclose(O.renorm_factor(wave, res0[0], 1.3 * res0[1] + 0.01), g[f"{tag}_renorm"][0], rtol=1e-14)
+
+
+def test_irregular_resample_and_collocation_restatement():
+    g = load_golden("transforms.npz")
+    x, y, q = g["irr_x"], g["irr_y"], g["irr_q"]
+    np.testing.assert_allclose(O.quintic_resample(x, y, q), g["irr_out"], rtol=0, atol=1e-15)
+    # the B-spline collocation restatement (what the HIP kernels implement) equals FITPACK
+    c, t = O.quintic_collocation_fit(x, y)
+    np.testing.assert_allclose(O.quintic_collocation_eval(t, c, q), g["irr_out"], rtol=0, atol=2e-13)
+
+
+@pytest.mark.parametrize("tag,m", [("a", 8), ("b", 4)])
+def test_emulator_matches_reference(tag, m):
+    g = load_golden("emulator.npz")
+    o = synth.make_order(N=256, m=m, seed=3)
+    var, ls = g[f"{tag}_variances"], g[f"{tag}_lengthscales"]
+    if tag == "a":
+        np.testing.assert_allclose(O.default_lengthscales(o["grid_points"], m), ls, rtol=1e-15)
+    v11 = O.emulator_v11(o["eigenspectra"], o["grid_points"], var, ls)
+    np.testing.assert_allclose(v11, g[f"{tag}_v11"], rtol=1e-12, atol=1e-12)
+    for i, q in enumerate(g[f"{tag}_queries"]):
+        mu, cov = O.emulator_query(o["grid_points"], q, var, ls, g[f"{tag}_v11"], o["w_hat"])
+        np.testing.assert_allclose(mu, g[f"{tag}_mu_{i}"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(cov, g[f"{tag}_cov_{i}"], rtol=1e-9, atol=1e-9)
+    with pytest.raises(ValueError):
+        O.emulator_query(o["grid_points"], [5999.0, 4.2, -0.3], var, ls, v11, o["w_hat"])
+
+
+def _small_params(o, name):
+    import gen_golden_cases as G
+
+    c = G.small_case_params(o, G.SMALL_CASES[name])
+    p = dict(grid=c["grid_params"])
+    for k in ("vz", "vsini", "log_scale", "cheb"):
+        if k in c:
+            p[k] = c[k]
+    if "global_cov" in c:
+        p["global_cov"] = (c["global_cov"]["log_amp"], c["global_cov"]["log_ls"])
+    if "local_cov" in c:
+        p["local_cov"] = [(k["mu"], k["log_amp"], k["log_sigma"]) for k in c["local_cov"]]
+    return p
+
+
+@pytest.mark.parametrize("name", ["full", "renorm", "bare", "no_local", "no_global", "two_local", "cheb4", "norm", "norm_renorm"])
+def test_small_model_matches_reference(name):
+    import gen_golden_cases as G
+    from scipy.interpolate import LinearNDInterpolator
+
+    g = load_golden("model_small.npz")
+    o = synth.make_order(N=256, m=4, seed=5)
+    oo = oracle_order(o)
+    np.testing.assert_allclose(oo.min_dv_wave, g["min_dv_wave"], rtol=1e-15)
+    np.testing.assert_allclose(oo.bulk_fluxes, g["bulk_fluxes"], rtol=0, atol=1e-15)
+    p = _small_params(o, name)
+    if G.SMALL_CASES[name].get("norm"):
+        # Emulator.norm_factor (emulator.py:429-444): scipy LinearNDInterpolator(rescale=True)
+        p["norm"] = float(LinearNDInterpolator(o["grid_points"], g["factors"], rescale=True)(np.asarray(p["grid"])))
+    lnl, logdet, sqmah, _ = O.log_likelihood(oo, p, return_parts=True)
+    flux, cov, scale = O.forward_model(oo, p)
+    ref = g[f"{name}_lnl"]
+    assert abs(lnl - ref[0]) <= 1e-10 * abs(ref[0])
+    assert abs(logdet - ref[1]) <= 1e-11 * abs(ref[1])
+    assert abs(sqmah - ref[2]) <= 1e-9 * abs(ref[2])
+    np.testing.assert_allclose(flux, g[f"{name}_flux"], rtol=1e-13)
+    # the rank-m emulator term cancels heavily off the diagonal: absolute floor ~ eps * max|C|
+    atol = 1e-12 * np.abs(cov).max()
+    if f"{name}_cov" in g:
+        np.testing.assert_allclose(cov, g[f"{name}_cov"], rtol=1e-12, atol=atol)
+    else:
+        np.testing.assert_allclose(cov[G.COV_ROWS], g[f"{name}_covrows"], rtol=1e-12, atol=atol)
+        np.testing.assert_allclose(cov.diagonal(), g[f"{name}_diag"], rtol=1e-12)
+
+
+def test_large_model_known_answers():
+    g = load_golden("model_large.npz")
+    o = synth.make_order(N=1024)
+    oo = oracle_order(o)
+    lnl, logdet, sqmah, _ = O.log_likelihood(oo, synth.vector_to_oracle_params(synth.centre_vector(o)), return_parts=True)
+    ref = g["n1024_lnl"]
+    assert abs(lnl - ref[0]) <= 1e-10 * abs(ref[0])
+    # survey's printed known answer
+    assert abs(lnl - 4124.8909586559) < 1e-8
+    P = g["n1024_batch_P"]
+    for p, want in zip(P[:3], g["n1024_batch_lnl"][:3]):
+        got = O.log_likelihood(oo, synth.vector_to_oracle_params(p))
+        assert abs(got - want) <= 1e-10 * abs(want)
+    np.testing.assert_allclose(P, synth.walker_ball(o, B=128)[: len(P)], rtol=0, atol=0)
