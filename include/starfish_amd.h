@@ -1,0 +1,208 @@
+/*
+ * starfish_amd.h -- C-ABI of the MI355X (gfx950) implementation of the Starfish per-MCMC-step
+ * log-likelihood path.
+ *
+ * The reference (Starfish-develop/Starfish v0.4.2) is pure Python and has NO FFI / plugin layer
+ * for this path: its boundary is the Python object API (SpectrumModel / Emulator and the free
+ * functions of Starfish.transforms / Starfish.models.kernels).  This header is therefore the
+ * boundary a maintainer would bind with ctypes; every entry point cites the
+ * reference function it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C, extern "C"; no torch / C++ types in any signature;
+ *   - every `d_*` argument is a DEVICE pointer to C-contiguous fp64 (or int32) owned by the
+ *     caller (e.g. torch.Tensor.data_ptr()); `h_*` arguments are HOST pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only ENQUEUE work,
+ *     they never synchronise -- the caller synchronises the stream before reading results;
+ *   - no allocation inside hot calls: scratch comes from the caller through the *_workspace_bytes
+ *     queries;
+ *   - return value: 0 = ok, <0 = SF_E* (bad argument / HIP failure).  Per-item numerical status is
+ *     reported LAPACK-style in `d_info[b]`: 0 ok, k>0 = order of the first non-positive pivot,
+ *     <0 = SF_INFO_* (parameter outside the emulator grid, non-positive vsini, ...).
+ *   - all matrices are row-major; the Cholesky factor is the LOWER triangle (A = L L^T), the strict
+ *     upper triangle is not referenced.
+ */
+#ifndef STARFISH_AMD_H
+#define STARFISH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_OK 0
+#define SF_EINVAL (-1)  /* bad argument */
+#define SF_ENOMEM (-2)  /* workspace too small / allocation failure */
+#define SF_EHIP (-3)    /* a HIP runtime call failed (sf_last_error() has the text) */
+#define SF_ENODEV (-4)  /* no gfx950 device visible */
+
+/* per-item d_info codes (<0) */
+#define SF_INFO_OUT_OF_GRID (-1) /* emulator queried outside its grid: emulator.py:377-378 */
+#define SF_INFO_BAD_VSINI (-2)   /* vsini <= 0: transforms.py:121-122 */
+#define SF_INFO_BAD_WEIGHT_COV (-3) /* Sigma_w not positive definite: spectrum_model.py:334 */
+
+#define SF_JITTER 1e-10 /* spectrum_model.py:399 */
+
+const char* sf_version(void);
+const char* sf_last_error(void);
+/* number of visible HIP devices (0 when none); never fails */
+int sf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Stand-alone stage entry points (used by the drop-in free functions and stage parity tests)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Starfish/models/kernels.py:7-41  global_covariance_matrix(wave, amplitude, lengthscale)
+ * d_out[n*n] = Hann-tapered Matern-3/2 in velocity distance (overwritten, full matrix). */
+int sf_global_cov(const double* d_wave, int n, double amplitude, double lengthscale,
+                  double* d_out, void* stream);
+
+/* Starfish/models/kernels.py:44-81  local_covariance_matrix(wave, amplitude, mu, sigma)
+ * accumulate != 0 adds into d_out (the sum over kernels of spectrum_model.py:353-360). */
+int sf_local_cov(const double* d_wave, int n, double amplitude, double mu, double sigma,
+                 int accumulate, double* d_out, void* stream);
+
+/* Starfish/transforms.py:93-134  rotational_broaden(wave, flux, vsini); dv = calculate_dv(wave)
+ * (Starfish/utils.py:8-22).  d_flux / d_out: rows x nf, nf a power of two.
+ * d_work: sf_fft_workspace_bytes(rows, nf). */
+int sf_rotational_broaden(const double* d_flux, int rows, int nf, double dv, double vsini,
+                          double* d_out, void* d_work, size_t work_bytes, void* stream);
+
+/* Starfish/transforms.py:45-90  instrumental_broaden(wave, flux, fwhm) */
+int sf_instrumental_broaden(const double* d_flux, int rows, int nf, double dv, double fwhm,
+                            double* d_out, void* d_work, size_t work_bytes, void* stream);
+
+size_t sf_fft_workspace_bytes(int rows, int nf);
+
+/* Starfish/transforms.py:11-42  resample(wave, flux, new_wave): interpolating k=5 spline
+ * (FITPACK knots x[0]x6, x[3:-3], x[-1]x6) per row, evaluated at new_wave.
+ * h_wave[n] is a HOST pointer (the collocation factor is built on the host once per grid);
+ * d_flux rows x n, d_new_wave[nq], d_out rows x nq.  d_work: sf_resample_workspace_bytes. */
+int sf_resample(const double* h_wave, int n, const double* d_flux, int rows,
+                const double* d_new_wave, int nq, double* d_out, void* d_work,
+                size_t work_bytes, void* stream);
+size_t sf_resample_workspace_bytes(int n, int rows);
+
+/* Starfish/transforms.py:271-304  chebyshev_correct(wave, flux, coeffs): flux * chebval(
+ * wave / wave_max, coeffs); h_coeffs[ncoef] is a HOST pointer (c0 must be 1 for 1-D use). */
+int sf_chebyshev_correct(const double* d_wave, int n, double wave_max, const double* d_flux,
+                         int rows, const double* h_coeffs, int ncoef, double* d_out,
+                         void* stream);
+
+/* scipy.linalg.cho_factor call site Starfish/models/spectrum_model.py:400 (LAPACK dpotrf).
+ * In-place batched lower Cholesky of `batch` matrices, matrix b at d_A + b*stride (doubles),
+ * n must be a multiple of 64 (callers pad with an identity block), row stride lda.
+ * d_work: sf_potrf_workspace_bytes(n, batch).  d_info[batch]. */
+int sf_potrf_batch(double* d_A, int n, int lda, int64_t stride, int batch, int* d_info,
+                   void* d_work, size_t work_bytes, void* stream);
+size_t sf_potrf_workspace_bytes(int n, int batch);
+
+/* Starfish/models/spectrum_model.py:401-404: logdet = 2 sum log L_ii and sqmah = R^T C^-1 R
+ * = |L^-1 R|^2 (one forward substitution; the reference's cho_solve does two).
+ * d_L as left by sf_potrf_batch; d_R: batch x ldr (ldr >= n, padded entries zero);
+ * d_work: sf_potrf_workspace_bytes(n, batch) (only touched when n*8 bytes exceed the LDS). */
+int sf_logdet_sqmah_batch(const double* d_L, int n, int lda, int64_t stride, int batch,
+                          const double* d_R, int ldr, void* d_work, size_t work_bytes,
+                          double* d_logdet, double* d_sqmah, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-order context: static data resident in HBM for the whole chain
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sf_ctx sf_ctx;
+
+/* All pointers are HOST pointers; everything is copied.  Mirrors what
+ * SpectrumModel.__init__ (Starfish/models/spectrum_model.py:126-181) and Emulator.__init__
+ * (Starfish/emulator/emulator.py:69-131) hold. */
+typedef struct sf_order_desc {
+    int32_t n;       /* masked data pixels N                     (spectrum.py:41-58)        */
+    int32_t nf;      /* length of min_dv_wave, a power of two    (utils.py:79-84)           */
+    int32_t m;       /* eigenspectra                             (emulator.py:104)          */
+    int32_t n_grid;  /* emulator parameter dimensions                                       */
+    int32_t M;       /* library grid points                                                  */
+    int32_t reserved;
+    const double* wave;         /* [n]   data.wave                                           */
+    const double* flux;         /* [n]   data.flux                                           */
+    const double* sigma;        /* [n]   data.sigma                                          */
+    const double* min_dv_wave;  /* [nf]  spectrum_model.py:151-153                           */
+    const double* bulk_fluxes;  /* [(m+2)*nf] eigenspectra; flux_mean; flux_std resampled on
+                                   min_dv_wave (spectrum_model.py:154-156)                   */
+    const double* grid_points;  /* [M*n_grid]                                                */
+    const double* variances;    /* [m]                                                       */
+    const double* lengthscales; /* [m*n_grid]                                                */
+    const double* v11;          /* [(m*M)^2]  emulator.py:123-128                            */
+    const double* w_hat;        /* [m*M]      component-major (emulator/_utils.py:19-21)     */
+} sf_order_desc;
+
+sf_ctx* sf_ctx_create(const sf_order_desc* desc, int device, int* err);
+void sf_ctx_destroy(sf_ctx* ctx);
+int sf_ctx_npad(const sf_ctx* ctx); /* N rounded up to the Cholesky leaf (64)              */
+int sf_ctx_lda(const sf_ctx* ctx);  /* row stride used for the covariance matrices          */
+
+/* Which optional parameters the model carries (the `"x" in self.params` tests of
+ * SpectrumModel.__call__, spectrum_model.py:290-363) and the layout of one parameter row:
+ *   [0] vsini  [1] vz  [2] log_scale  [3] norm factor (1 unless norm=True)
+ *   [4] global log_amp  [5] global log_ls
+ *   [6 .. 6+n_grid)             emulator grid parameters
+ *   [.. +n_cheb)                c1, c2, ...   (c0 == 1, spectrum_model.py:301-304)
+ *   [.. +3*n_local)             (mu, log_amp, log_sigma) per local kernel
+ * Unused slots are ignored.  Row stride = sf_param_stride(). */
+typedef struct sf_model_desc {
+    int32_t has_vsini;
+    int32_t has_vz;
+    int32_t has_log_scale; /* 0: renormalise by the integrated-flux ratio (spectrum_model.py:322-326) */
+    int32_t has_global;
+    int32_t n_local;
+    int32_t n_cheb;
+    int32_t use_sigma_w; /* 0 (default, parity): C_emu = X^T Sigma_w^-1 X as the code does
+                            (spectrum_model.py:334-335); 1: X^T Sigma_w X as the paper says  */
+    int32_t reserved;
+} sf_model_desc;
+
+int sf_param_stride(const sf_ctx* ctx, const sf_model_desc* model);
+
+/* scratch needed by the batched calls below for B walkers (covariance matrices included) */
+size_t sf_workspace_bytes(const sf_ctx* ctx, const sf_model_desc* model, int B);
+
+/* Emulator.__call__ (Starfish/emulator/emulator.py:330-394) for B parameter rows:
+ * d_mu[B*m], d_cov[B*m*m].  d_params: B x stride rows laid out as above. */
+int sf_emulator_query_batch(sf_ctx* ctx, const sf_model_desc* model, int B,
+                            const double* d_params, double* d_mu, double* d_cov, int* d_info,
+                            void* d_work, size_t work_bytes, void* stream);
+
+/* Transform chain of SpectrumModel.__call__ (spectrum_model.py:287-332): rotational_broaden,
+ * doppler_shift, resample, chebyshev_correct, eigenspectrum reconstruction and (re)scaling.
+ * Outputs: d_flux[B*n] scaled model flux, d_X[B*m*n] scaled eig*std rows, d_resid[B*n] =
+ * flux - data.flux, d_log_scale[B] (the `_log_scale` attribute).  Any output may be NULL. */
+int sf_transform_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const double* d_params,
+                       double* d_flux, double* d_X, double* d_resid, double* d_log_scale,
+                       int* d_info, void* d_work, size_t work_bytes, void* stream);
+
+/* SpectrumModel.__call__ (spectrum_model.py:277-365): d_flux[B*n], d_cov[B*n*n] (full symmetric
+ * matrices, WITHOUT the 1e-10 jitter, exactly what the reference returns). */
+int sf_forward_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const double* d_params,
+                     double* d_flux, double* d_cov, double* d_log_scale, int* d_info,
+                     void* d_work, size_t work_bytes, void* stream);
+
+/* SpectrumModel.log_likelihood without the prior term (spectrum_model.py:397-405):
+ * d_lnl[B] = -(logdet + sqmah)/2; optional d_logdet[B], d_sqmah[B], d_resid[B*n],
+ * d_log_scale[B].  Items with d_info[b] != 0 get lnl = -inf. */
+int sf_loglike_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const double* d_params,
+                     double* d_lnl, double* d_logdet, double* d_sqmah, double* d_resid,
+                     double* d_log_scale, int* d_info, void* d_work, size_t work_bytes,
+                     void* stream);
+
+/* Timing hooks for bench.py (process-global, not thread-safe): when enabled, the batched calls
+ * record HIP events on the caller's stream around each stage and around every MFMA update launch.
+ * sf_profile_read synchronises those events, returns the milliseconds accumulated since the last
+ * read in ms_by_stage[5] = {transforms, fill, mfma update kernel (k_gemm_nt), whole potrf, solve},
+ * the algorithmic flops and launch count of the MFMA update kernel, and the number of
+ * sf_loglike_batch calls; then it resets the counters. */
+int sf_profile_enable(int on);
+int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches, long* calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARFISH_AMD_H */

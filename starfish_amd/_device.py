@@ -1,0 +1,264 @@
+"""
+Device-side plumbing: PyTorch-ROCm tensors own the HBM buffers and the stream, the arithmetic is done
+by the HIP kernels behind the C-ABI (``_lib``).  Nothing here computes on the CPU.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+INFO_MESSAGES = {
+    -1: "Querying emulator outside of original parameter range.",
+    -2: "vsini must be positive",
+    -3: "emulator weight covariance is not positive definite",
+}
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def device_of(index=None):
+    torch = _torch()
+    if index is None:
+        index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    return torch.device("cuda", index)
+
+
+def to_dev(arr, dev):
+    torch = _torch()
+    a = np.ascontiguousarray(np.asarray(arr, dtype=np.float64))
+    return torch.from_numpy(a).to(dev)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream_ptr(dev):
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def empty(shape, dev, dtype=None):
+    torch = _torch()
+    return torch.empty(shape, dtype=dtype or torch.float64, device=dev)
+
+
+def workspace(nbytes, dev):
+    torch = _torch()
+    return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=dev)
+
+
+class DeviceOrder:
+    """One ``sf_ctx``: the static data of an order + emulator resident in HBM, and the batched calls."""
+
+    def __init__(
+        self,
+        wave,
+        flux,
+        sigma,
+        min_dv_wave,
+        bulk_fluxes,
+        grid_points,
+        variances,
+        lengthscales,
+        v11,
+        w_hat,
+        device=None,
+    ):
+        self.lib = _lib.require_gpu()
+        torch = _torch()
+        self.dev = device_of(device)
+        f8 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))  # noqa: E731
+        self._keep = [
+            f8(wave),
+            f8(flux),
+            f8(sigma),
+            f8(min_dv_wave),
+            f8(bulk_fluxes),
+            f8(grid_points),
+            f8(variances),
+            f8(lengthscales),
+            f8(v11),
+            f8(w_hat),
+        ]
+        w, fl, sg, mdw, bulk, grid, var, ls, v11a, wh = self._keep
+        self.n = int(w.shape[0])
+        self.nf = int(mdw.shape[0])
+        self.m = int(var.shape[0])
+        self.M, self.P = (int(grid.shape[0]), int(grid.shape[1]))
+        if self.n:
+            assert bulk.shape == (self.m + 2, self.nf), bulk.shape
+        assert v11a.shape == (self.m * self.M,) * 2
+        d = _lib.OrderDesc()
+        d.n, d.nf, d.m, d.n_grid, d.M = self.n, self.nf, self.m, self.P, self.M
+        d.wave, d.flux, d.sigma = map(_lib.as_double_p, (w, fl, sg))
+        d.min_dv_wave, d.bulk_fluxes = _lib.as_double_p(mdw), _lib.as_double_p(bulk)
+        d.grid_points, d.variances = _lib.as_double_p(grid), _lib.as_double_p(var)
+        d.lengthscales, d.v11, d.w_hat = map(_lib.as_double_p, (ls, v11a, wh))
+        err = C.c_int(0)
+        with torch.cuda.device(self.dev):
+            self.ctx = self.lib.sf_ctx_create(C.byref(d), self.dev.index or 0, C.byref(err))
+        if not self.ctx:
+            _lib.check(err.value or -1, "sf_ctx_create")
+        self.npad = self.lib.sf_ctx_npad(self.ctx)
+        self.lda = self.lib.sf_ctx_lda(self.ctx)
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.sf_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def model_desc(self, has_vsini, has_vz, has_log_scale, has_global, n_local, n_cheb, use_sigma_w=False):
+        md = _lib.ModelDesc()
+        md.has_vsini, md.has_vz = int(has_vsini), int(has_vz)
+        md.has_log_scale, md.has_global = int(has_log_scale), int(has_global)
+        md.n_local, md.n_cheb, md.use_sigma_w = int(n_local), int(n_cheb), int(use_sigma_w)
+        return md
+
+    def param_stride(self, md):
+        return self.lib.sf_param_stride(self.ctx, C.byref(md))
+
+    def workspace_bytes(self, md, B):
+        return self.lib.sf_workspace_bytes(self.ctx, C.byref(md), int(B))
+
+    def max_batch(self, md, reserve_fraction=0.15):
+        """Largest batch whose workspace fits the free HBM (leaving a safety margin)."""
+        torch = _torch()
+        free, _total = torch.cuda.mem_get_info(self.dev)
+        if self._ws is not None:
+            free += self._ws.numel()
+        budget = int(free * (1.0 - reserve_fraction))
+        per = self.workspace_bytes(md, 1)
+        return max(1, budget // max(per, 1))
+
+    def _work(self, md, B):
+        need = self.workspace_bytes(md, B)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = workspace(need, self.dev)
+        return self._ws
+
+    def release_workspace(self):
+        self._ws = None
+
+    # ------------------------------------------------------------------ batched calls
+    def loglike(self, md, params, want_resid=False, max_chunk=None):
+        """params: (B, stride) float64 (numpy or cuda tensor) in the C-ABI row layout.
+        Returns dict of numpy arrays: lnl, logdet, sqmah, log_scale, info (+ resid)."""
+        torch = _torch()
+        with torch.cuda.device(self.dev):
+            P = params if torch.is_tensor(params) else to_dev(params, self.dev)
+            B = int(P.shape[0])
+            chunk = min(B, max_chunk or B, self.max_batch(md))
+            lnl = empty((B,), self.dev)
+            logdet = empty((B,), self.dev)
+            sqmah = empty((B,), self.dev)
+            lsc = empty((B,), self.dev)
+            info = empty((B,), self.dev, torch.int32)
+            resid = empty((B, self.n), self.dev) if want_resid else None
+            s = stream_ptr(self.dev)
+            for lo in range(0, B, chunk):
+                hi = min(lo + chunk, B)
+                ws = self._work(md, hi - lo)
+                rc = self.lib.sf_loglike_batch(
+                    self.ctx, C.byref(md), hi - lo, ptr(P[lo:hi]), ptr(lnl[lo:hi]), ptr(logdet[lo:hi]),
+                    ptr(sqmah[lo:hi]), ptr(resid[lo:hi]) if want_resid else C.c_void_p(0), ptr(lsc[lo:hi]),
+                    ptr(info[lo:hi]), ptr(ws), ws.numel(), s,
+                )
+                _lib.check(rc, "sf_loglike_batch")
+            out = dict(
+                lnl=lnl.cpu().numpy(),
+                logdet=logdet.cpu().numpy(),
+                sqmah=sqmah.cpu().numpy(),
+                log_scale=lsc.cpu().numpy(),
+                info=info.cpu().numpy(),
+            )
+            if want_resid:
+                out["resid"] = resid.cpu().numpy()
+            return out
+
+    def loglike_device(self, md, P_dev, out_lnl, info=None):
+        """Enqueue-only variant for bench.py: device tensors in/out, no synchronisation."""
+        B = int(P_dev.shape[0])
+        ws = self._work(md, B)
+        rc = self.lib.sf_loglike_batch(
+            self.ctx, C.byref(md), B, ptr(P_dev), ptr(out_lnl), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0),
+            C.c_void_p(0), ptr(info), ptr(ws), ws.numel(), stream_ptr(self.dev),
+        )
+        _lib.check(rc, "sf_loglike_batch")
+
+    def forward(self, md, params):
+        """SpectrumModel.__call__ for B rows: flux (B, n), cov (B, n, n), log_scale, info."""
+        torch = _torch()
+        with torch.cuda.device(self.dev):
+            P = params if torch.is_tensor(params) else to_dev(params, self.dev)
+            B = int(P.shape[0])
+            flux = empty((B, self.n), self.dev)
+            cov = empty((B, self.n, self.n), self.dev)
+            lsc = empty((B,), self.dev)
+            info = empty((B,), self.dev, torch.int32)
+            ws = self._work(md, B)
+            rc = self.lib.sf_forward_batch(
+                self.ctx, C.byref(md), B, ptr(P), ptr(flux), ptr(cov), ptr(lsc), ptr(info), ptr(ws),
+                ws.numel(), stream_ptr(self.dev),
+            )
+            _lib.check(rc, "sf_forward_batch")
+            return dict(
+                flux=flux.cpu().numpy(), cov=cov.cpu().numpy(), log_scale=lsc.cpu().numpy(),
+                info=info.cpu().numpy(),
+            )
+
+    def transform(self, md, params):
+        torch = _torch()
+        with torch.cuda.device(self.dev):
+            P = params if torch.is_tensor(params) else to_dev(params, self.dev)
+            B = int(P.shape[0])
+            flux = empty((B, self.n), self.dev)
+            X = empty((B, self.m, self.n), self.dev)
+            resid = empty((B, self.n), self.dev)
+            lsc = empty((B,), self.dev)
+            info = empty((B,), self.dev, torch.int32)
+            ws = self._work(md, B)
+            rc = self.lib.sf_transform_batch(
+                self.ctx, C.byref(md), B, ptr(P), ptr(flux), ptr(X), ptr(resid), ptr(lsc), ptr(info),
+                ptr(ws), ws.numel(), stream_ptr(self.dev),
+            )
+            _lib.check(rc, "sf_transform_batch")
+            return dict(
+                flux=flux.cpu().numpy(), X=X.cpu().numpy(), resid=resid.cpu().numpy(),
+                log_scale=lsc.cpu().numpy(), info=info.cpu().numpy(),
+            )
+
+    def emulator_query(self, grid_params):
+        """grid_params: (B, P).  Returns mu (B, m), cov (B, m, m), info (B,)."""
+        torch = _torch()
+        gp = np.atleast_2d(np.asarray(grid_params, dtype=np.float64))
+        B = gp.shape[0]
+        md = self.model_desc(0, 0, 1, 0, 0, 0)
+        stride = self.param_stride(md)
+        rows = np.zeros((B, stride))
+        rows[:, 3] = 1.0
+        rows[:, 6 : 6 + self.P] = gp
+        with torch.cuda.device(self.dev):
+            P = to_dev(rows, self.dev)
+            mu = empty((B, self.m), self.dev)
+            cov = empty((B, self.m, self.m), self.dev)
+            info = empty((B,), self.dev, torch.int32)
+            ws = self._work(md, B)
+            rc = self.lib.sf_emulator_query_batch(
+                self.ctx, C.byref(md), B, ptr(P), ptr(mu), ptr(cov), ptr(info), ptr(ws), ws.numel(),
+                stream_ptr(self.dev),
+            )
+            _lib.check(rc, "sf_emulator_query_batch")
+            return mu.cpu().numpy(), cov.cpu().numpy(), info.cpu().numpy()

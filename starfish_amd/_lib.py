@@ -1,0 +1,159 @@
+"""
+ctypes binding of ``libstarfish_amd.so`` (include/starfish_amd.h).
+
+There is deliberately NO CPU fallback: every numerical entry point of this package goes through the
+HIP kernels, and :func:`require_gpu` raises when the shared library or a gfx950 device is missing.
+PyTorch is used only to own device memory / streams (``tensor.data_ptr()``).
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstarfish_amd.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class OrderDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32),
+        ("nf", C.c_int32),
+        ("m", C.c_int32),
+        ("n_grid", C.c_int32),
+        ("M", C.c_int32),
+        ("reserved", C.c_int32),
+        ("wave", c_double_p),
+        ("flux", c_double_p),
+        ("sigma", c_double_p),
+        ("min_dv_wave", c_double_p),
+        ("bulk_fluxes", c_double_p),
+        ("grid_points", c_double_p),
+        ("variances", c_double_p),
+        ("lengthscales", c_double_p),
+        ("v11", c_double_p),
+        ("w_hat", c_double_p),
+    ]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("has_vsini", C.c_int32),
+        ("has_vz", C.c_int32),
+        ("has_log_scale", C.c_int32),
+        ("has_global", C.c_int32),
+        ("n_local", C.c_int32),
+        ("n_cheb", C.c_int32),
+        ("use_sigma_w", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); kept in one table so the CPU test-suite can check that every symbol
+# declared in include/starfish_amd.h is exported.
+_VP = C.c_void_p
+SIGNATURES = {
+    "sf_version": (C.c_char_p, []),
+    "sf_last_error": (C.c_char_p, []),
+    "sf_device_count": (C.c_int, []),
+    "sf_global_cov": (C.c_int, [_VP, C.c_int, C.c_double, C.c_double, _VP, _VP]),
+    "sf_local_cov": (C.c_int, [_VP, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _VP, _VP]),
+    "sf_rotational_broaden": (
+        C.c_int,
+        [_VP, C.c_int, C.c_int, C.c_double, C.c_double, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_instrumental_broaden": (
+        C.c_int,
+        [_VP, C.c_int, C.c_int, C.c_double, C.c_double, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_fft_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sf_resample": (
+        C.c_int,
+        [c_double_p, C.c_int, _VP, C.c_int, _VP, C.c_int, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_resample_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sf_chebyshev_correct": (
+        C.c_int,
+        [_VP, C.c_int, C.c_double, _VP, C.c_int, c_double_p, C.c_int, _VP, _VP],
+    ),
+    "sf_potrf_batch": (
+        C.c_int,
+        [_VP, C.c_int, C.c_int, C.c_int64, C.c_int, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_potrf_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sf_logdet_sqmah_batch": (
+        C.c_int,
+        [_VP, C.c_int, C.c_int, C.c_int64, C.c_int, _VP, C.c_int, _VP, C.c_size_t, _VP, _VP, _VP],
+    ),
+    "sf_ctx_create": (_VP, [C.POINTER(OrderDesc), C.c_int, c_int_p]),
+    "sf_ctx_destroy": (None, [_VP]),
+    "sf_ctx_npad": (C.c_int, [_VP]),
+    "sf_ctx_lda": (C.c_int, [_VP]),
+    "sf_param_stride": (C.c_int, [_VP, C.POINTER(ModelDesc)]),
+    "sf_workspace_bytes": (C.c_size_t, [_VP, C.POINTER(ModelDesc), C.c_int]),
+    "sf_emulator_query_batch": (
+        C.c_int,
+        [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_transform_batch": (
+        C.c_int,
+        [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_forward_batch": (
+        C.c_int,
+        [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_loglike_batch": (
+        C.c_int,
+        [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_profile_enable": (C.c_int, [C.c_int]),
+    "sf_profile_read": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+}
+
+_lib = None
+
+
+class StarfishAMDError(RuntimeError):
+    """The HIP library is missing, no MI355X is visible, or a C-ABI call failed."""
+
+
+def load():
+    """Load the shared library (no GPU needed for loading / symbol checks)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StarfishAMDError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C starfish_amd/csrc`.  There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def require_gpu():
+    """Return the library, raising loudly when the HIP path cannot run."""
+    lib = load()
+    if lib.sf_device_count() <= 0:
+        raise StarfishAMDError(
+            "no HIP device visible: starfish_amd computes only on MI355X (gfx950); "
+            "there is no CPU fallback"
+        )
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sf_last_error().decode(errors="replace")
+        raise StarfishAMDError(f"{what} failed (code {rc}): {msg}")
+
+
+def as_double_p(arr):
+    return arr.ctypes.data_as(c_double_p)

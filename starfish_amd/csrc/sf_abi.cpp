@@ -1,0 +1,893 @@
+// C-ABI host layer (include/starfish_amd.h): context creation, workspace carving and the launch
+// sequences.  Host code only prepares constants that the reference recomputes on every call but that
+// do not depend on the walker (collocation factor of the fixed log-lambda grid, factor of the
+// constant v11); all per-walker arithmetic runs in the HIP kernels.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "sf_common.h"
+#include "sf_transform.h"
+
+// ----------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+void sf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* sf_last_error(void) { return g_err; }
+extern "C" const char* sf_version(void) { return "starfish_amd 0.1 (gfx950)"; }
+extern "C" int sf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ----------------------------------------------------------------------------------- profiling
+// Global, single-threaded timing hooks for bench.py (HIP events on the caller's stream).
+enum { PS_TRANSFORM = 0, PS_FILL, PS_GEMM, PS_POTRF, PS_SOLVE, PS_COUNT };
+struct ProfSpan {
+    hipEvent_t a, b;
+    int stage;
+};
+static struct {
+    int on = 0;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> pool;
+    double gemm_flops = 0.0;
+    long gemm_launches = 0;
+    long calls = 0;
+} g_prof;
+
+static hipEvent_t prof_event() {
+    hipEvent_t e;
+    if (!g_prof.pool.empty()) {
+        e = g_prof.pool.back();
+        g_prof.pool.pop_back();
+    } else {
+        (void)hipEventCreate(&e);
+    }
+    return e;
+}
+struct ProfScope {
+    hipStream_t s;
+    ProfSpan sp;
+    bool live;
+    ProfScope(hipStream_t st, int stage) : s(st), live(g_prof.on != 0) {
+        if (!live) return;
+        sp.stage = stage;
+        sp.a = prof_event();
+        sp.b = prof_event();
+        (void)hipEventRecord(sp.a, s);
+    }
+    ~ProfScope() {
+        if (!live) return;
+        (void)hipEventRecord(sp.b, s);
+        g_prof.spans.push_back(sp);
+    }
+};
+// called from sf_chol.hip around every k_gemm_nt launch
+void sf_prof_gemm_begin(hipStream_t s, double flops, void** tok) {
+    *tok = nullptr;
+    if (!g_prof.on) return;
+    ProfScope* p = new ProfScope(s, PS_GEMM);
+    g_prof.gemm_flops += flops;
+    g_prof.gemm_launches += 1;
+    *tok = p;
+}
+void sf_prof_gemm_end(void* tok) {
+    if (tok) delete (ProfScope*)tok;
+}
+
+extern "C" int sf_profile_enable(int on) {
+    g_prof.on = on;
+    return SF_OK;
+}
+extern "C" int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches, long* calls) {
+    double acc[PS_COUNT] = {0, 0, 0, 0, 0};
+    for (auto& sp : g_prof.spans) {
+        float ms = 0.f;
+        SF_HIP(hipEventSynchronize(sp.b));
+        SF_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+        acc[sp.stage] += ms;
+        g_prof.pool.push_back(sp.a);
+        g_prof.pool.push_back(sp.b);
+    }
+    g_prof.spans.clear();
+    if (ms_by_stage)
+        for (int i = 0; i < PS_COUNT; ++i) ms_by_stage[i] = acc[i];
+    if (gemm_flops) *gemm_flops = g_prof.gemm_flops;
+    if (gemm_launches) *gemm_launches = g_prof.gemm_launches;
+    if (calls) *calls = g_prof.calls;
+    g_prof.gemm_flops = 0.0;
+    g_prof.gemm_launches = 0;
+    g_prof.calls = 0;
+    return SF_OK;
+}
+
+// ------------------------------------------------------------------- host-side spline set-up
+// FITPACK knots of an interpolating k=5 spline through x[0..n): x0 x6, x[3:-3], x[n-1] x6.
+static void quintic_knots(const double* x, int n, std::vector<double>& t) {
+    t.resize((size_t)n + 6);
+    for (int i = 0; i < 6; ++i) t[i] = x[0];
+    for (int j = 3; j <= n - 4; ++j) t[j + 3] = x[j];
+    for (int i = 0; i < 6; ++i) t[n + i] = x[n - 1];
+}
+static void bspl6_host(const double* t, int ell, double x, double h[6]) {
+    double hh[5];
+    h[0] = 1.0;
+    for (int j = 1; j <= 5; ++j) {
+        for (int i = 0; i < j; ++i) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 1; i <= j; ++i) {
+            const int li = ell + i, lj = li - j;
+            const double f = hh[i - 1] / (t[li] - t[lj]);
+            h[i - 1] = h[i - 1] + f * (t[li] - x);
+            h[i] = f * (x - t[lj]);
+        }
+    }
+}
+// Band LU (no pivoting; B-spline collocation matrices are totally positive) of A[i][j] = B_j(x_i).
+// Outputs, per row j: Lf[j][k-1] = L[j][j-k], Uf[j][k-1] = U[j][j+k] (k = 1..SF_KB), rdiag[j] = 1/U[j][j].
+static int quintic_collocation_lu(const double* x, int n, std::vector<double>& t, std::vector<double>& Lf,
+                                  std::vector<double>& Uf, std::vector<double>& rdiag) {
+    if (n < 6) {
+        sf_set_error("resample needs at least 6 points, got %d", n);
+        return SF_EINVAL;
+    }
+    for (int i = 1; i < n; ++i)
+        if (!(x[i] > x[i - 1])) {
+            sf_set_error("resample: the source grid must be strictly increasing");
+            return SF_EINVAL;
+        }
+    quintic_knots(x, n, t);
+    const int W = 2 * SF_KB + 1;
+    std::vector<double> ab((size_t)n * W, 0.0);  // ab[i][col - i + KB]
+    int ell = 5;
+    for (int i = 0; i < n; ++i) {
+        while (ell < n - 1 && t[ell + 1] <= x[i]) ++ell;
+        double h[6];
+        bspl6_host(t.data(), ell, x[i], h);
+        for (int q = 0; q < 6; ++q) {
+            const int col = ell - 5 + q;
+            const int d = col - i + SF_KB;
+            if (h[q] != 0.0) {
+                if (d < 0 || d >= W) {
+                    sf_set_error("collocation bandwidth exceeded at row %d", i);
+                    return SF_EINVAL;
+                }
+                ab[(size_t)i * W + d] = h[q];
+            }
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        const double piv = ab[(size_t)k * W + SF_KB];
+        if (!(std::fabs(piv) > 0.0)) {
+            sf_set_error("singular spline collocation matrix at row %d", k);
+            return SF_EINVAL;
+        }
+        const int imax = (k + SF_KB < n - 1) ? k + SF_KB : n - 1;
+        for (int i = k + 1; i <= imax; ++i) {
+            double& lik = ab[(size_t)i * W + (k - i + SF_KB)];
+            if (lik == 0.0) continue;
+            lik /= piv;
+            for (int j = k + 1; j <= imax; ++j) {
+                const double ukj = ab[(size_t)k * W + (j - k + SF_KB)];
+                if (ukj != 0.0) ab[(size_t)i * W + (j - i + SF_KB)] -= lik * ukj;
+            }
+        }
+    }
+    Lf.assign((size_t)n * SF_KB, 0.0);
+    Uf.assign((size_t)n * SF_KB, 0.0);
+    rdiag.resize(n);
+    for (int j = 0; j < n; ++j) {
+        rdiag[j] = 1.0 / ab[(size_t)j * W + SF_KB];
+        for (int k = 1; k <= SF_KB; ++k) {
+            if (j - k >= 0) Lf[(size_t)j * SF_KB + k - 1] = ab[(size_t)j * W + (SF_KB - k)];
+            if (j + k < n) Uf[(size_t)j * SF_KB + k - 1] = ab[(size_t)j * W + (SF_KB + k)];
+        }
+    }
+    return SF_OK;
+}
+
+static void make_twiddles(int nf, std::vector<double>& tw) {
+    tw.resize((size_t)nf);  // nf/2 complex values
+    for (int k = 0; k < nf / 2; ++k) {
+        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)nf;
+        tw[2 * k] = (double)cosl(ang);
+        tw[2 * k + 1] = (double)sinl(ang);
+    }
+}
+
+// ----------------------------------------------------------------------------------- context
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        SF_HIP(hipMalloc(&p, bytes ? bytes : 8));
+        return SF_OK;
+    }
+    int upload(const void* src, size_t bytes) {
+        int rc = alloc(bytes);
+        if (rc) return rc;
+        SF_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return SF_OK;
+    }
+    template <typename T>
+    T* as() const {
+        return (T*)p;
+    }
+};
+
+struct sf_ctx {
+    int device = 0;
+    int n = 0, nf = 0, m = 0, P = 0, M = 0, npad = 0, lda = 0, mpad = 0, rows = 0;
+    int monotonic = 1;
+    double dv = 0.0, wave_max = 0.0;
+    DevBuf wave, flux, sigma, knots, spec, tw, Lf, Uf, rdiag, coef_static;
+    DevBuf grid, variances, lengthscales, gmin, gmax, alpha, Linv;
+};
+
+static double min_dv(const double* w, int n) {  // Starfish/utils.py:22
+    double best = INFINITY;
+    for (int i = 0; i + 1 < n; ++i) {
+        const double v = (w[i + 1] - w[i]) / w[i];
+        if (v < best) best = v;
+    }
+    return SF_C_KMS * best;
+}
+
+// Cholesky of v11 and the constants derived from it (emulator.py:387-388 solves with the constant
+// v11 on every call; here the factor is built once).
+static int emulator_constants(const double* v11, const double* w_hat, int N, std::vector<double>& alpha,
+                              std::vector<double>& Linv) {
+    std::vector<double> L((size_t)N * N, 0.0);
+    for (int i = 0; i < N; ++i) {
+        const double* ai = v11 + (size_t)i * N;
+        double* li = &L[(size_t)i * N];
+        for (int j = 0; j <= i; ++j) {
+            const double* lj = &L[(size_t)j * N];
+            double s = ai[j];
+            for (int k = 0; k < j; ++k) s -= li[k] * lj[k];
+            if (i == j) {
+                if (!(s > 0.0)) {
+                    sf_set_error("emulator v11 is not positive definite (row %d)", i);
+                    return SF_EINVAL;
+                }
+                li[j] = std::sqrt(s);
+            } else {
+                li[j] = s / lj[j];
+            }
+        }
+    }
+    // W = Linv^T (row-major W[j][i] = Linv[i][j]) so the inner products run over contiguous memory
+    std::vector<double> W((size_t)N * N, 0.0);
+    for (int j = 0; j < N; ++j) {
+        double* wj = &W[(size_t)j * N];
+        for (int i = j; i < N; ++i) {
+            const double* li = &L[(size_t)i * N];
+            double s = (i == j) ? 1.0 : 0.0;
+            for (int k = j; k < i; ++k) s -= li[k] * wj[k];
+            wj[i] = s / li[i];
+        }
+    }
+    Linv.assign((size_t)N * N, 0.0);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j <= i; ++j) Linv[(size_t)i * N + j] = W[(size_t)j * N + i];
+    // alpha = Linv^T (Linv w_hat)
+    std::vector<double> y(N, 0.0);
+    for (int i = 0; i < N; ++i) {
+        double s = 0.0;
+        for (int j = 0; j <= i; ++j) s += Linv[(size_t)i * N + j] * w_hat[j];
+        y[i] = s;
+    }
+    alpha.assign(N, 0.0);
+    for (int j = 0; j < N; ++j) {
+        double s = 0.0;
+        for (int i = j; i < N; ++i) s += W[(size_t)j * N + i] * y[i];
+        alpha[j] = s;
+    }
+    return SF_OK;
+}
+
+extern "C" sf_ctx* sf_ctx_create(const sf_order_desc* d, int device, int* err) {
+    int rc_dummy = 0;
+    int& rc = err ? *err : rc_dummy;
+    rc = SF_OK;
+    auto fail = [&](int code) -> sf_ctx* {
+        rc = code;
+        return nullptr;
+    };
+    // n == 0 builds an emulator-only context (Emulator.__call__ without a SpectrumModel)
+    const bool order_ok = d && (d->n == 0 || (d->n >= 2 && d->nf >= 8 && !(d->nf & (d->nf - 1)) && d->wave &&
+                                               d->flux && d->sigma && d->min_dv_wave && d->bulk_fluxes));
+    if (!d || !order_ok || d->m < 1 || d->m > SF_MAX_M || d->n_grid < 1 || d->M < 1 || !d->grid_points ||
+        !d->variances || !d->lengthscales || !d->v11 || !d->w_hat) {
+        sf_set_error("sf_ctx_create: bad descriptor");
+        return fail(SF_EINVAL);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) {
+        sf_set_error("sf_ctx_create: no HIP device %d", device);
+        return fail(SF_ENODEV);
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        sf_set_error("hipSetDevice(%d) failed", device);
+        return fail(SF_EHIP);
+    }
+    sf_ctx* c = new sf_ctx();
+    c->device = device;
+    c->n = d->n;
+    c->nf = d->nf;
+    c->m = d->m;
+    c->P = d->n_grid;
+    c->M = d->M;
+    c->rows = d->m + 2;
+    c->npad = (int)sf_align_up((size_t)d->n, SF_LEAF);
+    c->lda = c->npad + 16;  // breaks the power-of-two row stride (HBM channel camping)
+    c->mpad = (int)sf_align_up((size_t)d->m, 4);
+    const bool has_order = d->n > 0;
+    c->dv = has_order ? min_dv(d->min_dv_wave, d->nf) : 0.0;
+    c->wave_max = has_order ? d->wave[0] : 0.0;
+    for (int i = 0; i < d->n; ++i) {
+        if (d->wave[i] > c->wave_max) c->wave_max = d->wave[i];
+        if (i && !(d->wave[i] > d->wave[i - 1])) c->monotonic = 0;
+    }
+#define TRY(x)              \
+    do {                    \
+        int rc__ = (x);     \
+        if (rc__) {         \
+            delete c;       \
+            return fail(rc__); \
+        }                   \
+    } while (0)
+    const size_t nb = sizeof(double) * (size_t)d->n;
+    if (has_order) {
+    TRY(c->wave.upload(d->wave, nb));
+    TRY(c->flux.upload(d->flux, nb));
+    TRY(c->sigma.upload(d->sigma, nb));
+
+    std::vector<double> t, Lf, Uf, rdiag, tw;
+    TRY(quintic_collocation_lu(d->min_dv_wave, d->nf, t, Lf, Uf, rdiag));
+    TRY(c->knots.upload(t.data(), sizeof(double) * t.size()));
+    TRY(c->Lf.upload(Lf.data(), sizeof(double) * Lf.size()));
+    TRY(c->Uf.upload(Uf.data(), sizeof(double) * Uf.size()));
+    TRY(c->rdiag.upload(rdiag.data(), sizeof(double) * rdiag.size()));
+    make_twiddles(d->nf, tw);
+    TRY(c->tw.upload(tw.data(), sizeof(double) * tw.size()));
+
+    // static spline coefficients of the un-broadened rows, stored [nf][rows]
+    {
+        std::vector<double> ct((size_t)d->nf * c->rows);
+        for (int r = 0; r < c->rows; ++r)
+            for (int j = 0; j < d->nf; ++j) ct[(size_t)j * c->rows + r] = d->bulk_fluxes[(size_t)r * d->nf + j];
+        TRY(c->coef_static.upload(ct.data(), sizeof(double) * ct.size()));
+        TRY(sf_launch_spline_solve(c->coef_static.as<double>(), 1, c->rows, 0, 1, c->rows, d->nf,
+                                   c->Lf.as<double>(), c->Uf.as<double>(), c->rdiag.as<double>(), 0));
+    }
+    // half spectra of the static rows (rfft once; every walker only multiplies and inverts)
+    {
+        DevBuf bulk, scratch;
+        TRY(bulk.upload(d->bulk_fluxes, sizeof(double) * (size_t)c->rows * d->nf));
+        TRY(c->spec.alloc(sizeof(double2) * (size_t)c->rows * (d->nf / 2 + 1)));
+        const size_t sb = sf_fft_scratch_bytes(c->rows, d->nf);
+        if (sb) TRY(scratch.alloc(sb));
+        TRY(sf_launch_rfft_rows(bulk.as<double>(), c->rows, d->nf, c->tw.as<double2>(), c->spec.as<double2>(),
+                                scratch.as<double2>(), 0));
+        if (hipDeviceSynchronize() != hipSuccess) {
+            sf_set_error("context set-up kernels failed: %s", hipGetErrorString(hipGetLastError()));
+            delete c;
+            return fail(SF_EHIP);
+        }
+    }
+    }  // has_order
+    // emulator constants
+    {
+        const int N = d->m * d->M;
+        std::vector<double> alpha, Linv, gmin(d->n_grid), gmax(d->n_grid);
+        TRY(emulator_constants(d->v11, d->w_hat, N, alpha, Linv));
+        for (int p = 0; p < d->n_grid; ++p) {
+            gmin[p] = gmax[p] = d->grid_points[p];
+            for (int j = 1; j < d->M; ++j) {
+                const double v = d->grid_points[(size_t)j * d->n_grid + p];
+                if (v < gmin[p]) gmin[p] = v;
+                if (v > gmax[p]) gmax[p] = v;
+            }
+        }
+        TRY(c->grid.upload(d->grid_points, sizeof(double) * (size_t)d->M * d->n_grid));
+        TRY(c->variances.upload(d->variances, sizeof(double) * d->m));
+        TRY(c->lengthscales.upload(d->lengthscales, sizeof(double) * (size_t)d->m * d->n_grid));
+        TRY(c->gmin.upload(gmin.data(), sizeof(double) * d->n_grid));
+        TRY(c->gmax.upload(gmax.data(), sizeof(double) * d->n_grid));
+        TRY(c->alpha.upload(alpha.data(), sizeof(double) * N));
+        TRY(c->Linv.upload(Linv.data(), sizeof(double) * (size_t)N * N));
+    }
+#undef TRY
+    return c;
+}
+
+extern "C" void sf_ctx_destroy(sf_ctx* c) { delete c; }
+extern "C" int sf_ctx_npad(const sf_ctx* c) { return c ? c->npad : SF_EINVAL; }
+extern "C" int sf_ctx_lda(const sf_ctx* c) { return c ? c->lda : SF_EINVAL; }
+
+static int model_ok(const sf_ctx* c, const sf_model_desc* mdl) {
+    if (!c || !mdl || mdl->n_local < 0 || mdl->n_cheb < 0) {
+        sf_set_error("bad context / model descriptor");
+        return SF_EINVAL;
+    }
+    return SF_OK;
+}
+extern "C" int sf_param_stride(const sf_ctx* c, const sf_model_desc* mdl) {
+    if (model_ok(c, mdl)) return SF_EINVAL;
+    return 6 + c->P + mdl->n_cheb + 3 * mdl->n_local;
+}
+
+// ----------------------------------------------------------------------------------- workspace
+struct Carve {
+    char* base;
+    size_t off = 0, cap;
+    Carve(void* p, size_t bytes) : base((char*)p), cap(bytes) {}
+    template <typename T>
+    T* take(size_t count) {
+        off = sf_align_up(off, 256);
+        T* r = base ? (T*)(base + off) : nullptr;
+        off += sizeof(T) * count;
+        return r;
+    }
+};
+struct Work {
+    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *Xraw, *fraw, *resid, *Y, *C, *ztrsv;
+    double2* fft;
+    int *info_e, *info_c;
+    size_t bytes;
+};
+static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, size_t cap, bool need_C) {
+    Carve k(p, cap);
+    Work w;
+    const size_t b = (size_t)B;
+    w.mu = k.take<double>(b * c->m);
+    w.Lw = k.take<double>(b * c->m * c->m);
+    w.zs = k.take<double>(b * c->m * c->M * c->m);
+    w.scale = k.take<double>(b);
+    w.logdet = k.take<double>(b);
+    w.sqmah = k.take<double>(b);
+    w.info_e = k.take<int>(b);
+    w.info_c = k.take<int>(b);
+    w.coef = mdl->has_vsini ? k.take<double>(b * c->nf * c->rows) : nullptr;
+    const size_t fb = mdl->has_vsini ? sf_fft_scratch_bytes(B * c->rows, c->nf) : 0;
+    w.fft = fb ? k.take<double2>(fb / sizeof(double2)) : nullptr;
+    w.Xraw = k.take<double>(b * c->m * c->npad);
+    w.fraw = k.take<double>(b * c->npad);
+    w.resid = k.take<double>(b * c->npad);
+    w.Y = k.take<double>(b * c->mpad * c->npad);
+    w.ztrsv = k.take<double>(b * c->npad);
+    w.C = need_C ? k.take<double>(b * (size_t)c->npad * c->lda) : nullptr;
+    w.bytes = sf_align_up(k.off, 256);
+    return w;
+}
+extern "C" size_t sf_workspace_bytes(const sf_ctx* c, const sf_model_desc* mdl, int B) {
+    if (model_ok(c, mdl) || B <= 0) return 0;
+    return carve(c, mdl, B, nullptr, 0, true).bytes;
+}
+
+// ----------------------------------------------------------------------------------- stages
+static int run_emulator(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params, const Work& w,
+                        double* d_mu, double* d_cov, double* d_Lw, int* d_info, hipStream_t s) {
+    sf_emu_args e;
+    e.params = d_params;
+    e.pstride = sf_param_stride(c, mdl);
+    e.off_grid = 6;
+    e.m = c->m;
+    e.M = c->M;
+    e.P = c->P;
+    e.grid = c->grid.as<double>();
+    e.variances = c->variances.as<double>();
+    e.lengthscales = c->lengthscales.as<double>();
+    e.gmin = c->gmin.as<double>();
+    e.gmax = c->gmax.as<double>();
+    e.alpha = c->alpha.as<double>();
+    e.Linv = c->Linv.as<double>();
+    e.zscratch = w.zs;
+    e.mu = d_mu;
+    e.cov = d_cov;
+    e.Lw = d_Lw;
+    e.info = d_info;
+    return sf_launch_emulator(e, B, s);
+}
+
+// emulator + transform chain -> unscaled X / flux, scale, then residual / Y
+static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params, const Work& w,
+                          double* d_flux_out, double* d_X_out, double* d_resid_out, double* d_log_scale,
+                          bool want_Y, hipStream_t s) {
+    const int pstride = sf_param_stride(c, mdl);
+    SF_HIP(hipMemsetAsync(w.info_e, 0, sizeof(int) * (size_t)B, s));
+    int rc = run_emulator(c, mdl, B, d_params, w, w.mu, nullptr, w.Lw, w.info_e, s);
+    if (rc) return rc;
+    const double* coef = c->coef_static.as<double>();
+    if (mdl->has_vsini) {
+        sf_broaden_args a;
+        a.in = nullptr;
+        a.spec = c->spec.as<double2>();
+        a.B = B;
+        a.rows = c->rows;
+        a.nf = c->nf;
+        a.tw = c->tw.as<double2>();
+        a.dv = c->dv;
+        a.kind = 1;
+        a.params = d_params;
+        a.pstride = pstride;
+        a.poff = 0;
+        a.scalar_param = 0.0;
+        a.out = w.coef;
+        a.ob = (int64_t)c->nf * c->rows;
+        a.orow = 1;
+        a.oelem = c->rows;
+        a.gscratch = w.fft;
+        a.info = w.info_e;
+        rc = sf_launch_broaden(a, s);
+        if (rc) return rc;
+        rc = sf_launch_spline_solve(w.coef, B, c->rows, (int64_t)c->nf * c->rows, 1, c->rows, c->nf,
+                                    c->Lf.as<double>(), c->Uf.as<double>(), c->rdiag.as<double>(), s);
+        if (rc) return rc;
+        coef = w.coef;
+    }
+    sf_eval_args ev;
+    ev.wave = c->wave.as<double>();
+    ev.knots = c->knots.as<double>();
+    ev.coef = coef;
+    ev.coef_batched = mdl->has_vsini ? 1 : 0;
+    ev.params = d_params;
+    ev.mu = w.mu;
+    ev.X = w.Xraw;
+    ev.flux = w.fraw;
+    ev.info = w.info_e;
+    ev.n = c->n;
+    ev.nf = c->nf;
+    ev.m = c->m;
+    ev.ldx = c->npad;
+    ev.pstride = pstride;
+    ev.has_vz = mdl->has_vz;
+    ev.n_cheb = mdl->n_cheb;
+    ev.off_cheb = 6 + c->P;
+    ev.wave_max = c->wave_max;
+    rc = sf_launch_eval_rows(ev, B, s);
+    if (rc) return rc;
+
+    sf_scale_args sc;
+    sc.wave = c->wave.as<double>();
+    sc.dflux = c->flux.as<double>();
+    sc.flux = w.fraw;
+    sc.params = d_params;
+    sc.scale = w.scale;
+    sc.log_scale_out = d_log_scale;
+    sc.n = c->n;
+    sc.ldx = c->npad;
+    sc.pstride = pstride;
+    sc.has_log_scale = mdl->has_log_scale;
+    rc = sf_launch_scale(sc, B, s);
+    if (rc) return rc;
+
+    sf_resid_args r;
+    r.dflux = c->flux.as<double>();
+    r.flux = w.fraw;
+    r.X = w.Xraw;
+    r.scale = w.scale;
+    r.Lw = w.Lw;
+    r.info = w.info_e;
+    r.resid = w.resid;
+    r.Y = want_Y ? w.Y : nullptr;
+    r.flux_out = d_flux_out;
+    r.X_out = d_X_out;
+    r.n = c->n;
+    r.m = c->m;
+    r.mpad = c->mpad;
+    r.ldx = c->npad;
+    r.ldy = c->npad;
+    r.use_sigma_w = mdl->use_sigma_w;
+    rc = sf_launch_resid_y(r, B, s);
+    if (rc) return rc;
+    if (d_resid_out)
+        SF_HIP(hipMemcpy2DAsync(d_resid_out, sizeof(double) * c->n, w.resid, sizeof(double) * c->npad,
+                                sizeof(double) * c->n, B, hipMemcpyDeviceToDevice, s));
+    return SF_OK;
+}
+
+static sf_fill_args fill_args(sf_ctx* c, const sf_model_desc* mdl, const double* d_params, const Work& w) {
+    sf_fill_args f;
+    f.wave = c->wave.as<double>();
+    f.sigma = c->sigma.as<double>();
+    f.Y = w.Y;
+    f.params = d_params;
+    f.n = c->n;
+    f.npad = c->npad;
+    f.mpad = c->mpad;
+    f.ldy = c->npad;
+    f.pstride = sf_param_stride(c, mdl);
+    f.has_global = mdl->has_global;
+    f.n_local = mdl->n_local;
+    f.off_global = 4;
+    f.off_local = 6 + c->P + mdl->n_cheb;
+    f.monotonic = c->monotonic;
+    return f;
+}
+
+static int check_work(const sf_ctx* c, const sf_model_desc* mdl, int B, const void* d_work, size_t have,
+                      bool need_C) {
+    if (model_ok(c, mdl)) return SF_EINVAL;
+    if (B <= 0 || !d_work) {
+        sf_set_error("bad batch size / workspace");
+        return SF_EINVAL;
+    }
+    const size_t need = carve(c, mdl, B, nullptr, 0, need_C).bytes;
+    if (have < need) {
+        sf_set_error("workspace too small: have %zu, need %zu", have, need);
+        return SF_ENOMEM;
+    }
+    return SF_OK;
+}
+
+extern "C" int sf_emulator_query_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params,
+                                       double* d_mu, double* d_cov, int* d_info, void* d_work,
+                                       size_t work_bytes, void* stream) {
+    int rc = check_work(c, mdl, B, d_work, work_bytes, false);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    Work w = carve(c, mdl, B, d_work, work_bytes, false);
+    int* info = d_info ? d_info : w.info_e;
+    SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s));
+    return run_emulator(c, mdl, B, d_params, w, d_mu ? d_mu : w.mu, d_cov, w.Lw, info, s);
+}
+
+extern "C" int sf_transform_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params,
+                                  double* d_flux, double* d_X, double* d_resid, double* d_log_scale,
+                                  int* d_info, void* d_work, size_t work_bytes, void* stream) {
+    int rc = check_work(c, mdl, B, d_work, work_bytes, false);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    Work w = carve(c, mdl, B, d_work, work_bytes, false);
+    rc = run_transforms(c, mdl, B, d_params, w, d_flux, d_X, d_resid, d_log_scale, false, s);
+    if (rc) return rc;
+    if (d_info) SF_HIP(hipMemcpyAsync(d_info, w.info_e, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return SF_OK;
+}
+
+extern "C" int sf_forward_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params,
+                                double* d_flux, double* d_cov, double* d_log_scale, int* d_info,
+                                void* d_work, size_t work_bytes, void* stream) {
+    int rc = check_work(c, mdl, B, d_work, work_bytes, false);
+    if (rc) return rc;
+    if (!d_cov) {
+        sf_set_error("sf_forward_batch: d_cov is required");
+        return SF_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    Work w = carve(c, mdl, B, d_work, work_bytes, false);
+    rc = run_transforms(c, mdl, B, d_params, w, d_flux, nullptr, nullptr, d_log_scale, true, s);
+    if (rc) return rc;
+    sf_fill_args f = fill_args(c, mdl, d_params, w);
+    f.C = d_cov;
+    f.lda = c->n;
+    f.stride = (int64_t)c->n * c->n;
+    f.lower_only = 0;
+    f.add_jitter = 0;
+    rc = sf_launch_fill(f, B, s);
+    if (rc) return rc;
+    if (d_info) SF_HIP(hipMemcpyAsync(d_info, w.info_e, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return SF_OK;
+}
+
+extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params,
+                                double* d_lnl, double* d_logdet, double* d_sqmah, double* d_resid,
+                                double* d_log_scale, int* d_info, void* d_work, size_t work_bytes,
+                                void* stream) {
+    int rc = check_work(c, mdl, B, d_work, work_bytes, true);
+    if (rc) return rc;
+    if (!d_lnl) {
+        sf_set_error("sf_loglike_batch: d_lnl is required");
+        return SF_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    Work w = carve(c, mdl, B, d_work, work_bytes, true);
+    g_prof.calls += 1;
+    {
+        ProfScope ps(s, PS_TRANSFORM);
+        rc = run_transforms(c, mdl, B, d_params, w, nullptr, nullptr, d_resid, d_log_scale, true, s);
+        if (rc) return rc;
+    }
+    const int64_t stride = (int64_t)c->npad * c->lda;
+    {
+        ProfScope ps(s, PS_FILL);
+        sf_fill_args f = fill_args(c, mdl, d_params, w);
+        f.C = w.C;
+        f.lda = c->lda;
+        f.stride = stride;
+        f.lower_only = 1;
+        f.add_jitter = 1;
+        rc = sf_launch_fill(f, B, s);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(s, PS_POTRF);
+        rc = sf_launch_potrf(w.C, c->npad, c->lda, stride, B, w.info_c, s);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(s, PS_SOLVE);
+        rc = sf_launch_logdet_sqmah(w.C, c->npad, c->lda, stride, B, w.resid, c->npad, w.ztrsv, w.logdet,
+                                    w.sqmah, s);
+        if (rc) return rc;
+        rc = sf_launch_finish(B, w.logdet, w.sqmah, w.info_e, w.info_c, d_lnl, d_info, s);
+        if (rc) return rc;
+    }
+    if (d_logdet) SF_HIP(hipMemcpyAsync(d_logdet, w.logdet, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, s));
+    if (d_sqmah) SF_HIP(hipMemcpyAsync(d_sqmah, w.sqmah, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return SF_OK;
+}
+
+// --------------------------------------------------------------------- stand-alone entry points
+extern "C" int sf_global_cov(const double* d_wave, int n, double amplitude, double lengthscale, double* d_out,
+                             void* stream) {
+    if (!d_wave || !d_out || n < 0) {
+        sf_set_error("sf_global_cov: bad argument");
+        return SF_EINVAL;
+    }
+    return sf_launch_global_cov(d_wave, n, amplitude, lengthscale, d_out, (hipStream_t)stream);
+}
+extern "C" int sf_local_cov(const double* d_wave, int n, double amplitude, double mu, double sigma,
+                            int accumulate, double* d_out, void* stream) {
+    if (!d_wave || !d_out || n < 0) {
+        sf_set_error("sf_local_cov: bad argument");
+        return SF_EINVAL;
+    }
+    return sf_launch_local_cov(d_wave, n, amplitude, mu, sigma, accumulate, d_out, (hipStream_t)stream);
+}
+
+extern "C" size_t sf_fft_workspace_bytes(int rows, int nf) {
+    if (rows <= 0 || nf <= 0) return 0;
+    return sf_align_up(sizeof(double) * (size_t)nf, 256) + sf_fft_scratch_bytes(rows, nf) + 256;
+}
+static int broaden_free(const double* d_flux, int rows, int nf, double dv, int kind, double param,
+                        double* d_out, void* d_work, size_t work_bytes, hipStream_t s) {
+    if (!d_flux || !d_out || rows <= 0 || !d_work || work_bytes < sf_fft_workspace_bytes(rows, nf)) {
+        sf_set_error("broaden: bad argument or workspace");
+        return SF_EINVAL;
+    }
+    if (nf < 2 || (nf & (nf - 1))) {
+        sf_set_error("broaden: nf=%d must be a power of two", nf);
+        return SF_EINVAL;
+    }
+    Carve k(d_work, work_bytes);
+    double* twd = k.take<double>((size_t)nf);
+    const size_t fb = sf_fft_scratch_bytes(rows, nf);
+    double2* scratch = fb ? k.take<double2>(fb / sizeof(double2)) : nullptr;
+    std::vector<double> tw;
+    make_twiddles(nf, tw);
+    // pageable host -> device copy: synchronous w.r.t. the host buffer, safe to free afterwards
+    SF_HIP(hipMemcpyAsync(twd, tw.data(), sizeof(double) * (size_t)nf, hipMemcpyHostToDevice, s));
+    SF_HIP(hipStreamSynchronize(s));
+    sf_broaden_args a;
+    a.in = d_flux;
+    a.spec = nullptr;
+    a.B = 1;
+    a.rows = rows;
+    a.nf = nf;
+    a.tw = (const double2*)twd;
+    a.dv = dv;
+    a.kind = kind;
+    a.params = nullptr;
+    a.pstride = 0;
+    a.poff = 0;
+    a.scalar_param = param;
+    a.out = d_out;
+    a.ob = 0;
+    a.orow = nf;
+    a.oelem = 1;
+    a.gscratch = scratch;
+    a.info = nullptr;
+    return sf_launch_broaden(a, s);
+}
+extern "C" int sf_rotational_broaden(const double* d_flux, int rows, int nf, double dv, double vsini,
+                                     double* d_out, void* d_work, size_t work_bytes, void* stream) {
+    if (!(vsini > 0.0)) {
+        sf_set_error("vsini must be positive");  // transforms.py:121-122
+        return SF_EINVAL;
+    }
+    return broaden_free(d_flux, rows, nf, dv, 1, vsini, d_out, d_work, work_bytes, (hipStream_t)stream);
+}
+extern "C" int sf_instrumental_broaden(const double* d_flux, int rows, int nf, double dv, double fwhm,
+                                       double* d_out, void* d_work, size_t work_bytes, void* stream) {
+    if (fwhm < 0.0) {
+        sf_set_error("FWHM must be non-negative");  // transforms.py:78-79
+        return SF_EINVAL;
+    }
+    return broaden_free(d_flux, rows, nf, dv, 2, fwhm, d_out, d_work, work_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t sf_resample_workspace_bytes(int n, int rows) {
+    if (n <= 0 || rows <= 0) return 0;
+    // knots, Lf, Uf, rdiag, coefficient rows
+    return sf_align_up(sizeof(double) * ((size_t)n + 6), 256) + 2 * sf_align_up(sizeof(double) * (size_t)n * SF_KB, 256) +
+           sf_align_up(sizeof(double) * (size_t)n, 256) + sf_align_up(sizeof(double) * (size_t)n * rows, 256) + 1024;
+}
+extern "C" int sf_resample(const double* h_wave, int n, const double* d_flux, int rows, const double* d_new_wave,
+                           int nq, double* d_out, void* d_work, size_t work_bytes, void* stream) {
+    if (!h_wave || !d_flux || !d_new_wave || !d_out || rows <= 0 || nq < 0 || !d_work ||
+        work_bytes < sf_resample_workspace_bytes(n, rows)) {
+        sf_set_error("sf_resample: bad argument or workspace");
+        return SF_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<double> t, Lf, Uf, rdiag;
+    int rc = quintic_collocation_lu(h_wave, n, t, Lf, Uf, rdiag);
+    if (rc) return rc;
+    Carve k(d_work, work_bytes);
+    double* dt = k.take<double>(t.size());
+    double* dL = k.take<double>(Lf.size());
+    double* dU = k.take<double>(Uf.size());
+    double* dr = k.take<double>(rdiag.size());
+    double* dc = k.take<double>((size_t)n * rows);
+    SF_HIP(hipMemcpyAsync(dt, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, s));
+    SF_HIP(hipMemcpyAsync(dL, Lf.data(), sizeof(double) * Lf.size(), hipMemcpyHostToDevice, s));
+    SF_HIP(hipMemcpyAsync(dU, Uf.data(), sizeof(double) * Uf.size(), hipMemcpyHostToDevice, s));
+    SF_HIP(hipMemcpyAsync(dr, rdiag.data(), sizeof(double) * rdiag.size(), hipMemcpyHostToDevice, s));
+    SF_HIP(hipMemcpyAsync(dc, d_flux, sizeof(double) * (size_t)n * rows, hipMemcpyDeviceToDevice, s));
+    SF_HIP(hipStreamSynchronize(s));  // the host vectors go out of scope below
+    rc = sf_launch_spline_solve(dc, 1, rows, 0, n, 1, n, dL, dU, dr, s);
+    if (rc) return rc;
+    if (nq == 0) return SF_OK;
+    return sf_launch_spline_eval(dc, rows, n, dt, d_new_wave, nq, d_out, s);
+}
+
+extern "C" int sf_chebyshev_correct(const double* d_wave, int n, double wave_max, const double* d_flux, int rows,
+                                    const double* h_coeffs, int ncoef, double* d_out, void* stream) {
+    if (!d_wave || !d_flux || !h_coeffs || !d_out || n < 0 || rows <= 0 || ncoef < 1 || ncoef > 64) {
+        sf_set_error("sf_chebyshev_correct: bad argument");
+        return SF_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // coefficients ride in a small device buffer owned by this call (stream-ordered alloc/free)
+    double* dco = nullptr;
+    SF_HIP(hipMalloc((void**)&dco, sizeof(double) * 64));
+    hipError_t e = hipMemcpyAsync(dco, h_coeffs, sizeof(double) * ncoef, hipMemcpyHostToDevice, s);
+    int rc = SF_OK;
+    if (e != hipSuccess) rc = SF_EHIP;
+    if (!rc) rc = sf_launch_cheb_rows(d_wave, n, wave_max, d_flux, rows, dco, ncoef, d_out, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(dco);
+    return rc;
+}
+
+extern "C" size_t sf_potrf_workspace_bytes(int n, int batch) {
+    if (n <= 0 || batch <= 0) return 0;
+    return sf_align_up(sizeof(double) * (size_t)n * batch, 256) + 256;
+}
+extern "C" int sf_potrf_batch(double* d_A, int n, int lda, int64_t stride, int batch, int* d_info, void* d_work,
+                              size_t work_bytes, void* stream) {
+    (void)d_work;
+    (void)work_bytes;
+    if (!d_A || !d_info) {
+        sf_set_error("sf_potrf_batch: bad argument");
+        return SF_EINVAL;
+    }
+    ProfScope ps((hipStream_t)stream, PS_POTRF);
+    return sf_launch_potrf(d_A, n, lda, stride, batch, d_info, (hipStream_t)stream);
+}
+extern "C" int sf_logdet_sqmah_batch(const double* d_L, int n, int lda, int64_t stride, int batch,
+                                     const double* d_R, int ldr, void* d_work, size_t work_bytes,
+                                     double* d_logdet, double* d_sqmah, void* stream) {
+    if (!d_L || !d_R || !d_logdet || !d_sqmah || ldr < n) {
+        sf_set_error("sf_logdet_sqmah_batch: bad argument");
+        return SF_EINVAL;
+    }
+    double* z = nullptr;
+    if (d_work && work_bytes >= sf_potrf_workspace_bytes(n, batch)) z = (double*)d_work;
+    ProfScope ps((hipStream_t)stream, PS_SOLVE);
+    return sf_launch_logdet_sqmah(d_L, n, lda, stride, batch, d_R, ldr, z, d_logdet, d_sqmah,
+                                  (hipStream_t)stream);
+}

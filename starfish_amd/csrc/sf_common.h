@@ -1,0 +1,63 @@
+// Shared declarations for the gfx950 kernels and the C-ABI host layer (internal; not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/starfish_amd.h"
+
+#define SF_LEAF 64        // Cholesky leaf block (potrf / trsm granularity); matrices padded to it
+#define SF_NB 256         // outer left-looking panel width
+#define SF_C_KMS 2.99792458e5
+
+typedef double sf_d4 __attribute__((ext_vector_type(4)));
+
+void sf_set_error(const char* fmt, ...);
+
+#define SF_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            sf_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return SF_EHIP;                                                              \
+        }                                                                                \
+    } while (0)
+
+#define SF_LAUNCH_CHECK()                                                                \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) {                                                          \
+            sf_set_error("%s:%d launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return SF_EHIP;                                                              \
+        }                                                                                \
+    } while (0)
+
+static inline size_t sf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// profiling hooks (sf_abi.cpp)
+void sf_prof_gemm_begin(hipStream_t s, double flops, void** tok);
+void sf_prof_gemm_end(void* tok);
+
+// ---- launchers implemented in the .hip files (all enqueue on `s`, never synchronise) ----------
+// sf_chol.hip
+int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, hipStream_t s);
+int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int batch,
+                           const double* R, int ldr, double* zscratch, double* logdet, double* sqmah, hipStream_t s);
+
+// sf_fill.hip
+struct sf_fill_args {
+    const double* wave;    // [n]
+    const double* sigma;   // [n]
+    const double* Y;       // [B][mpad][ldy]  (rank-m factor rows, zero padded to mpad)
+    const double* params;  // [B][pstride]
+    double* C;             // [B] x stride
+    int n, npad, lda, mpad, ldy, pstride;
+    int64_t stride;
+    int has_global, n_local, off_global, off_local;
+    int lower_only;        // 1: only tiles touching the lower triangle, identity padding written
+    int add_jitter;        // 1: + SF_JITTER on the diagonal
+    int monotonic;         // wave sorted ascending -> band culling allowed
+};
+int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);
+int sf_launch_global_cov(const double* wave, int n, double amp, double ls, double* out, hipStream_t s);
+int sf_launch_local_cov(const double* wave, int n, double amp, double mu, double sigma, int accumulate,
+                        double* out, hipStream_t s);

@@ -1,0 +1,278 @@
+// Fused covariance fill for gfx950: one pass writes
+//     C[b] = Y_b^T Y_b  +  diag(sigma^2)  +  K_global  +  sum_k K_local,k  (+ 1e-10 I)
+// replacing the dense temporaries of the reference:
+//   Starfish/models/spectrum_model.py:334-363  (X^T Sigma_w^-1 X, fill_diagonal, cov += ...)
+//   Starfish/models/kernels.py:7-41            (global_covariance_matrix)
+//   Starfish/models/kernels.py:44-81           (local_covariance_matrix)
+//   Starfish/models/spectrum_model.py:399      (jitter)
+// The rank-m emulator term runs on v_mfma_f64_16x16x4_f64 (the MFMA row index is mapped to matrix
+// COLUMNS so that every lane owns 4 consecutive columns -> 32-byte stores, full 128-B lines per
+// 4 lanes); the banded/patch kernels are evaluated only in wave sub-tiles that intersect their
+// support.  Compiled with -ffp-contract=off: element formulas keep the reference's operation order.
+#include "sf_common.h"
+
+#define FT 64  // tile edge per workgroup (4 waves, 32 x 32 each)
+
+__device__ __forceinline__ int sf_xcd_remap_f(int bid, int nblk) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// kernels.py:27-40 with wx = wave[col], wy = wave[row]
+__device__ __forceinline__ double sf_matern_elem(double w_row, double w_col, double amp, double ls,
+                                                 double r0) {
+    const double r = SF_C_KMS / 2 * fabs((w_col - w_row) / (w_col + w_row));
+    if (!(r <= r0)) return 0.0;
+    const double taper = 0.5 + 0.5 * cos(M_PI * r / r0);
+    const double s3 = 1.7320508075688772;  // numpy.sqrt(3)
+    return taper * amp * (1 + s3 * r / ls) * exp(-s3 * r / ls);
+}
+
+// kernels.py:68-80 with x = met[col], y = met[row]
+__device__ __forceinline__ double sf_local_elem(double d_row, double d_col, double amp, double sigma,
+                                                double r0) {
+    const double r_tap = fmax(d_col, d_row);
+    if (!(r_tap <= r0)) return 0.0;
+    const double r2 = d_col * d_col + d_row * d_row;
+    const double taper = 0.5 + 0.5 * cos(M_PI * r_tap / r0);
+    return taper * amp * exp(-0.5 * r2 / (sigma * sigma));
+}
+
+__device__ __forceinline__ double sf_local_metric(double w, double mu) {
+    return SF_C_KMS / mu * fabs(w - mu);  // kernels.py:69
+}
+
+#define SF_MAX_LOCAL 8
+
+__global__ __launch_bounds__(256) void k_fill(sf_fill_args a, int nt) {
+    const int id = sf_xcd_remap_f(blockIdx.x, gridDim.x);
+    const int tiles = nt * nt;
+    const int b = id / tiles;
+    const int t = id - b * tiles;
+    const int tm = t / nt, tn = t - tm * nt;
+    if (a.lower_only && tn > tm) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
+    const int nout = a.lower_only ? a.npad : a.n;  // extent of the stored matrix
+    if (R0 >= nout || C0 >= nout) return;
+    if (a.lower_only && C0 > R0 + 31) return;
+    const int gam = lane & 15, q = lane >> 4;
+
+    const double* __restrict__ Yb = a.Y + (int64_t)b * a.mpad * a.ldy;
+    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
+    double* __restrict__ Cb = a.C + (int64_t)b * a.stride;
+
+    // ---- rank-m term: acc[ti][tj] element (row R0+ti*16+gam, cols C0+tj*16+4q+r)
+    sf_d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+    const int colperm = 4 * (gam & 3) + (gam >> 2);
+    for (int kk = 0; kk < a.mpad; kk += 4) {
+        const double* yk = Yb + (int64_t)(kk + q) * a.ldy;
+        double brow[2], acol[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            brow[i] = yk[R0 + i * 16 + gam];
+            acol[i] = yk[C0 + i * 16 + colperm];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[j], brow[i], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- which structured kernels touch this 32 x 32 sub-tile (wave-uniform decisions)
+    const int rlo = R0, rhi = min(R0 + 31, a.n - 1);
+    const int clo = C0, chi = min(C0 + 31, a.n - 1);
+    const bool real_tile = (R0 < a.n) && (C0 < a.n);
+    bool do_glob = false;
+    double g_amp = 0, g_ls = 1, g_r0 = 0;
+    if (a.has_global && real_tile) {
+        g_amp = exp(P[a.off_global]);      // spectrum_model.py:343
+        g_ls = exp(P[a.off_global + 1]);   // spectrum_model.py:344
+        g_r0 = 6 * g_ls;                   // kernels.py:29
+        do_glob = true;
+        if (a.monotonic) {
+            // closest (row, col) pair of the sub-tile in wavelength
+            double wr, wc;
+            if (rlo > chi) { wr = a.wave[rlo]; wc = a.wave[chi]; }
+            else if (clo > rhi) { wr = a.wave[rhi]; wc = a.wave[clo]; }
+            else { wr = wc = 1.0; }
+            const double rmin = SF_C_KMS / 2 * fabs((wc - wr) / (wc + wr));
+            do_glob = rmin <= g_r0 * (1 + 1e-9);
+        }
+    }
+    // ---- epilogue: structured terms in the reference's order of additions, then store
+    const bool vec_ok = (a.lda & 1) == 0;
+    int rows[2];
+    double w_rows[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        rows[ti] = R0 + ti * 16 + gam;
+        w_rows[ti] = (rows[ti] < a.n) ? a.wave[rows[ti]] : 1.0;
+    }
+    double w_cols[2][4];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = C0 + tj * 16 + 4 * q + r;
+            w_cols[tj][r] = (col < a.n) ? a.wave[col] : 1.0;
+        }
+
+    if (real_tile) {
+        // spectrum_model.py:338  diagonal noise, then :348 global kernel
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rows[ti], col = C0 + tj * 16 + 4 * q + r;
+                    if (row < a.n && col < a.n) {
+                        double val = acc[ti][tj][r];
+                        if (row == col) {
+                            const double sg = a.sigma[row];
+                            val = val + sg * sg;
+                        }
+                        if (do_glob)
+                            val = val + sf_matern_elem(w_rows[ti], w_cols[tj][r], g_amp, g_ls, g_r0);
+                        acc[ti][tj][r] = val;
+                    }
+                }
+        // spectrum_model.py:353-363  _loc_cov = 0 + K_0 + K_1 + ... ; cov += _loc_cov
+        if (a.n_local > 0) {
+            sf_d4 loc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) loc[i][j] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+            bool any = false;
+            for (int k = 0; k < a.n_local; ++k) {
+                const double mu = P[a.off_local + 3 * k];
+                const double amp = exp(P[a.off_local + 3 * k + 1]);  // spectrum_model.py:356
+                const double sig = exp(P[a.off_local + 3 * k + 2]);  // spectrum_model.py:357
+                const double r0 = 4 * sig;                           // kernels.py:73
+                bool hit = true;
+                if (a.monotonic) {
+                    // smallest metric inside an index range is at the ends or across mu
+                    auto dmin = [&](int lo, int hi) {
+                        const double wl = a.wave[lo], wh = a.wave[hi];
+                        if (wl <= mu && mu <= wh) return 0.0;
+                        return fmin(sf_local_metric(wl, mu), sf_local_metric(wh, mu));
+                    };
+                    hit = (dmin(rlo, rhi) <= r0 * (1 + 1e-9)) && (dmin(clo, chi) <= r0 * (1 + 1e-9));
+                }
+                if (!hit) continue;
+                any = true;
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    const double d_row = sf_local_metric(w_rows[ti], mu);
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            loc[ti][tj][r] = loc[ti][tj][r] +
+                                             sf_local_elem(d_row, sf_local_metric(w_cols[tj][r], mu), amp,
+                                                           sig, r0);
+                }
+            }
+            if (any) {
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = acc[ti][tj] + loc[ti][tj];
+            }
+        }
+    }
+
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int row = rows[ti];
+        if (row >= nout) continue;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int col0 = C0 + tj * 16 + 4 * q;
+            if (col0 >= nout) continue;
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = col0 + r;
+                double val = acc[ti][tj][r];
+                if (row < a.n && col < a.n) {
+                    if (row == col && a.add_jitter) val = val + SF_JITTER;  // spectrum_model.py:399
+                } else {
+                    val = (row == col) ? 1.0 : 0.0;  // identity padding up to the Cholesky leaf
+                }
+                v[r] = val;
+            }
+            double* dst = Cb + (int64_t)row * a.lda + col0;
+            if (vec_ok && col0 + 3 < nout) {
+                *(double2*)dst = make_double2(v[0], v[1]);
+                *(double2*)(dst + 2) = make_double2(v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col0 + r < nout) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
+    if (a.n_local > SF_MAX_LOCAL) {
+        sf_set_error("at most %d local kernels are supported", SF_MAX_LOCAL);
+        return SF_EINVAL;
+    }
+    const int nout = a.lower_only ? a.npad : a.n;
+    const int nt = (nout + FT - 1) / FT;
+    const long long nblk = (long long)nt * nt * B;
+    if (nblk > 0x7fffffffLL) {
+        sf_set_error("fill grid too large");
+        return SF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)nblk), dim3(256), 0, s, a, nt);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+// ------------------------------------------------------------ stand-alone kernels (free functions)
+__global__ __launch_bounds__(256) void k_global_cov(const double* __restrict__ wave, int n, double amp,
+                                                    double ls, double* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (col >= n) return;
+    out[(int64_t)row * n + col] = sf_matern_elem(wave[row], wave[col], amp, ls, 6 * ls);
+}
+
+__global__ __launch_bounds__(256) void k_local_cov(const double* __restrict__ wave, int n, double amp,
+                                                   double mu, double sigma, int accumulate,
+                                                   double* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (col >= n) return;
+    const double v = sf_local_elem(sf_local_metric(wave[row], mu), sf_local_metric(wave[col], mu), amp,
+                                   sigma, 4 * sigma);
+    double* o = out + (int64_t)row * n + col;
+    *o = accumulate ? (*o + v) : v;
+}
+
+int sf_launch_global_cov(const double* wave, int n, double amp, double ls, double* out, hipStream_t s) {
+    if (n <= 0) return SF_OK;
+    hipLaunchKernelGGL(k_global_cov, dim3((n + 255) / 256, n), dim3(256), 0, s, wave, n, amp, ls, out);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_local_cov(const double* wave, int n, double amp, double mu, double sigma, int accumulate,
+                        double* out, hipStream_t s) {
+    if (n <= 0) return SF_OK;
+    hipLaunchKernelGGL(k_local_cov, dim3((n + 255) / 256, n), dim3(256), 0, s, wave, n, amp, mu, sigma,
+                       accumulate, out);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}

@@ -1,0 +1,635 @@
+// Per-spectrum transform kernels for gfx950 (all fp64; compiled with -ffp-contract=off so element
+// formulas keep the reference's operation order):
+//   k_broaden        rfft -> kernel multiply -> irfft     Starfish/transforms.py:45-90, 93-134
+//   k_spline_solve   banded (LU) solve of the k=5 B-spline collocation system  (transforms.py:39-42,
+//                    FITPACK curfit with s=0; knots x[0]x6, x[3:-3], x[-1]x6)
+//   k_eval_rows      doppler_shift + spline evaluation + chebyshev_correct + eigenspectrum
+//                    reconstruction      transforms.py:137-158, 271-304; spectrum_model.py:293-313
+//   k_scale, k_resid_y   rescale / renorm, residual and the rank-m factor Y   spectrum_model.py:316-335
+//   k_emulator       GP conditional of the PCA weights      Starfish/emulator/emulator.py:330-394
+#include "sf_common.h"
+#include "sf_transform.h"
+
+// --------------------------------------------------------------------------------------- FFT
+// In-place radix-2 decimation-in-time FFT on `buf` (LDS or global), input already bit-reversed.
+// tw[k] = exp(-2 pi i k / nf), k < nf/2; this transform has length L = nf >> shift... (L == nf here)
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__device__ void sf_fft_inplace(double2* buf, int L, const double2* __restrict__ tw, bool inverse) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    int ls = 0;  // log2(half-size)
+    for (int s = 1; s < L; s <<= 1, ++ls) {
+        const int twstep = L / (2 * s);
+        for (int idx = tid; idx < L / 2; idx += nth) {
+            const int j = idx & (s - 1);
+            const int i0 = ((idx >> ls) << (ls + 1)) + j;
+            const int i1 = i0 + s;
+            double2 wv = tw[j * twstep];
+            if (inverse) wv.y = -wv.y;
+            const double2 u = buf[i0];
+            const double2 v = cmul(wv, buf[i1]);
+            buf[i0] = make_double2(u.x + v.x, u.y + v.y);
+            buf[i1] = make_double2(u.x - v.x, u.y - v.y);
+        }
+        __syncthreads();
+    }
+}
+
+// Decimation-in-frequency forward FFT: natural-order input, BIT-REVERSED output (so the product
+// with a real symmetric multiplier feeds the DIT inverse above without any permutation pass).
+__device__ void sf_fft_dif_forward(double2* buf, int L, const double2* __restrict__ tw) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    int ls = 0;
+    while ((2 << ls) < L) ++ls;  // log2(L/2)
+    for (int s = L >> 1; s >= 1; s >>= 1, --ls) {
+        const int twstep = L / (2 * s);
+        for (int idx = tid; idx < L / 2; idx += nth) {
+            const int j = idx & (s - 1);
+            const int i0 = ((idx >> ls) << (ls + 1)) + j;
+            const int i1 = i0 + s;
+            const double2 wv = tw[j * twstep];
+            const double2 u = buf[i0], v = buf[i1];
+            buf[i0] = make_double2(u.x + v.x, u.y + v.y);
+            buf[i1] = cmul(wv, make_double2(u.x - v.x, u.y - v.y));
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ unsigned sf_bitrev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
+
+// Gray (2005) rotational kernel, transforms.py:129-131, and the Gaussian profile, transforms.py:84-85
+__device__ __forceinline__ double sf_rot_mult(int k, double val, double vsini) {
+    if (k == 0) return 1.0;
+    const double freq = k * val;
+    const double ub = 2.0 * M_PI * vsini * freq;
+    return j1(ub) / ub - 3 * cos(ub) / (2 * (ub * ub)) + 3.0 * sin(ub) / (2 * (ub * ub * ub));
+}
+__device__ __forceinline__ double sf_inst_mult(int k, double val, double fwhm) {
+    const double freq = k * val;
+    const double sigma = fwhm / 2.355;
+    const double a = M_PI * sigma * freq;
+    return exp(-2 * (a * a));
+}
+
+// One workgroup per spectrum row.
+//   FWD   : true  -> the row is real input `in` (rows x nf) and is transformed first;
+//           false -> `spec` holds the precomputed half spectrum (rows_static x (nf/2+1)).
+//   kind  : 0 none (multiplier 1), 1 rotational (param = vsini), 2 instrumental (param = fwhm)
+// Output element j of row r of item b is written at out[b*ob + r*orow + j*oelem].
+template <bool FWD, bool USE_LDS>
+__global__ __launch_bounds__(256) void k_broaden(const double* __restrict__ in,
+                                                 const double2* __restrict__ spec, int rows, int nf,
+                                                 const double2* __restrict__ tw, double dv, int kind,
+                                                 const double* __restrict__ params, int pstride,
+                                                 int poff, double scalar_param, double* __restrict__ out,
+                                                 int64_t ob, int64_t orow, int64_t oelem,
+                                                 double2* __restrict__ gscratch, int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double2 lbuf[];
+    const int row = blockIdx.x, b = blockIdx.y;
+    double2* buf = USE_LDS ? lbuf : gscratch + ((int64_t)b * rows + row) * nf;
+    const int tid = threadIdx.x;
+    int bits = 0;
+    while ((1 << bits) < nf) ++bits;
+    const int nh = nf / 2;
+
+    double param = scalar_param;
+    if (params) param = params[(int64_t)b * pstride + poff];
+    if (kind == 1 && !(param > 0.0)) {  // transforms.py:121-122
+        if (tid == 0 && info) atomicCAS(&info[b], 0, SF_INFO_BAD_VSINI);
+        return;
+    }
+    const double val = 1.0 / (nf * dv);  // numpy.fft.rfftfreq
+
+    if (FWD) {
+        const double* x = in + ((int64_t)b * rows + row) * nf;
+        for (int j = tid; j < nf; j += 256) buf[j] = make_double2(x[j], 0.0);
+        __syncthreads();
+        sf_fft_dif_forward(buf, nf, tw);
+        // position p holds frequency k = bitrev(p); the multiplier is real and even in k
+        for (int p = tid; p < nf; p += 256) {
+            const int k = (int)sf_bitrev((unsigned)p, bits);
+            const int kk = (k <= nh) ? k : nf - k;
+            double mult = 1.0;
+            if (kind == 1) mult = sf_rot_mult(kk, val, param);
+            else if (kind == 2) mult = sf_inst_mult(kk, val, param);
+            double2 X = buf[p];
+            X.x *= mult;
+            X.y *= mult;
+            if (kk == 0 || kk == nh) X.y = 0.0;  // c2r ignores the imaginary part of DC / Nyquist
+            buf[p] = X;
+        }
+    } else {
+        // X_k (k <= nf/2) and conj(X_{nf-k}) go straight to their bit-reversed slots
+        for (int k = tid; k <= nh; k += 256) {
+            double2 X = spec[(int64_t)row * (nh + 1) + k];
+            double mult = 1.0;
+            if (kind == 1) mult = sf_rot_mult(k, val, param);
+            else if (kind == 2) mult = sf_inst_mult(k, val, param);
+            X.x *= mult;
+            X.y *= mult;
+            if (k == 0 || k == nh) X.y = 0.0;
+            buf[sf_bitrev(k, bits)] = X;
+            if (k != 0 && k != nh) buf[sf_bitrev(nf - k, bits)] = make_double2(X.x, -X.y);
+        }
+    }
+    __syncthreads();
+    sf_fft_inplace(buf, nf, tw, true);
+    const double inv_n = 1.0 / nf;
+    double* o = out + (int64_t)b * ob + (int64_t)row * orow;
+    for (int j = tid; j < nf; j += 256) o[(int64_t)j * oelem] = buf[j].x * inv_n;
+}
+
+// Forward half spectrum of static rows (context creation): spec[row][k], k <= nf/2.
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_rfft_rows(const double* __restrict__ in, int nf,
+                                                   const double2* __restrict__ tw,
+                                                   double2* __restrict__ spec,
+                                                   double2* __restrict__ gscratch) {
+    extern __shared__ __attribute__((aligned(16))) double2 lbuf[];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    double2* buf = USE_LDS ? lbuf : gscratch + (int64_t)row * nf;
+    int bits = 0;
+    while ((1 << bits) < nf) ++bits;
+    const double* x = in + (int64_t)row * nf;
+    for (int j = tid; j < nf; j += 256) buf[sf_bitrev(j, bits)] = make_double2(x[j], 0.0);
+    __syncthreads();
+    sf_fft_inplace(buf, nf, tw, false);
+    for (int k = tid; k <= nf / 2; k += 256) spec[(int64_t)row * (nf / 2 + 1) + k] = buf[k];
+}
+
+// ------------------------------------------------------------------------- banded spline solve
+// One lane per right-hand side; element j of system s lives at data[s_base(s) + j*estride].
+// Systems are grouped: s = b*rows + r -> base = b*bstride + r*rstride.
+__global__ __launch_bounds__(64) void k_spline_solve(double* __restrict__ data, int nsys, int rows,
+                                                     int64_t bstride, int64_t rstride, int64_t estride,
+                                                     int n, const double* __restrict__ Lf,
+                                                     const double* __restrict__ Uf,
+                                                     const double* __restrict__ rdiag) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= nsys) return;
+    const int b = s / rows, r = s - b * rows;
+    double* x = data + (int64_t)b * bstride + (int64_t)r * rstride;
+    // forward: y_j = b_j - sum_{k=1..KL} L[j][k] y_{j-k}
+    double y1 = 0, y2 = 0, y3 = 0, y4 = 0, y5 = 0;
+    for (int j = 0; j < n; ++j) {
+        const double* l = Lf + (int64_t)j * SF_KB;
+        double v = x[(int64_t)j * estride];
+        v -= l[4] * y5;
+        v -= l[3] * y4;
+        v -= l[2] * y3;
+        v -= l[1] * y2;
+        v -= l[0] * y1;
+        x[(int64_t)j * estride] = v;
+        y5 = y4; y4 = y3; y3 = y2; y2 = y1; y1 = v;
+    }
+    // backward: c_j = (y_j - sum_{k=1..KU} U[j][k] c_{j+k}) / U[j][j]
+    double c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    for (int j = n - 1; j >= 0; --j) {
+        const double* u = Uf + (int64_t)j * SF_KB;
+        double v = x[(int64_t)j * estride];
+        v -= u[4] * c5;
+        v -= u[3] * c4;
+        v -= u[2] * c3;
+        v -= u[1] * c2;
+        v -= u[0] * c1;
+        v *= rdiag[j];
+        x[(int64_t)j * estride] = v;
+        c5 = c4; c4 = c3; c3 = c2; c2 = c1; c1 = v;
+    }
+}
+
+// ------------------------------------------------------------------------ spline evaluation
+// FITPACK fpbspl: the six non-zero quintic B-splines on [t[ell], t[ell+1]) at x, knots scaled by s.
+__device__ __forceinline__ void sf_bspl6(const double* __restrict__ t, double s, int ell, double x,
+                                         double h[6]) {
+    double tk[12];  // t[ell-5 .. ell+6] scaled
+#pragma unroll
+    for (int i = 0; i < 12; ++i) tk[i] = t[ell - 5 + i] * s;
+    double hh[5];
+    h[0] = 1.0;
+#pragma unroll
+    for (int j = 1; j <= 5; ++j) {
+#pragma unroll
+        for (int i = 0; i < j; ++i) hh[i] = h[i];
+        h[0] = 0.0;
+#pragma unroll
+        for (int i = 1; i <= j; ++i) {
+            // li = ell + i, lj = li - j  -> tk index = (.) - (ell - 5)
+            const double tli = tk[5 + i], tlj = tk[5 + i - j];
+            const double f = hh[i - 1] / (tli - tlj);
+            h[i - 1] = h[i - 1] + f * (tli - x);
+            h[i] = f * (x - tlj);
+        }
+    }
+}
+
+// splev interval search: largest ell in [5, ncoef-1] with t[ell]*s <= x
+__device__ __forceinline__ int sf_find_interval(const double* __restrict__ t, double s, int ncoef, double x) {
+    int lo = 5, hi = ncoef - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t[mid] * s <= x) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// numpy.polynomial.chebyshev.chebval (Clenshaw) with coefficient vector [1, c1, c2, ...]
+__device__ __forceinline__ double sf_chebval(double x, const double* __restrict__ c, int nc /* incl. c0 */,
+                                             double c0first) {
+    auto coef = [&](int i) { return i == 0 ? c0first : c[i - 1]; };
+    double a0, a1;
+    if (nc == 1) { a0 = coef(0); a1 = 0.0; }
+    else if (nc == 2) { a0 = coef(0); a1 = coef(1); }
+    else {
+        const double x2 = 2 * x;
+        a0 = coef(nc - 2);
+        a1 = coef(nc - 1);
+        for (int i = 3; i <= nc; ++i) {
+            const double tmp = a0;
+            a0 = coef(nc - i) - a1;
+            a1 = tmp + a1 * x2;
+        }
+    }
+    return a0 + a1 * x;
+}
+
+// Generic resample (free function): out[r][q] = spline_r(xq[q]); coefficients coef[r][j] row-major.
+__global__ __launch_bounds__(256) void k_spline_eval(const double* __restrict__ coef, int rows, int ncoef,
+                                                     const double* __restrict__ t,
+                                                     const double* __restrict__ xq, int nq,
+                                                     double* __restrict__ out) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const double x = xq[q];
+    const int ell = sf_find_interval(t, 1.0, ncoef, x);
+    double h[6];
+    sf_bspl6(t, 1.0, ell, x, h);
+    for (int r = 0; r < rows; ++r) {
+        const double* c = coef + (int64_t)r * ncoef + ell - 5;
+        double sp = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sp = sp + c[j] * h[j];
+        out[(int64_t)r * nq + q] = sp;
+    }
+}
+
+// Fused: Doppler-scaled spline evaluation of the m+2 rows, Chebyshev multiply, reconstruction.
+__global__ __launch_bounds__(256) void k_eval_rows(sf_eval_args a) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= a.n) return;
+    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
+    if (a.info && a.info[b] != 0) return;
+    const double x = a.wave[i];
+    double s = 1.0;
+    if (a.has_vz) {
+        const double vz = P[1];
+        s = sqrt((SF_C_KMS + vz) / (SF_C_KMS - vz));  // transforms.py:157
+    }
+    const int ell = sf_find_interval(a.knots, s, a.nf, x);
+    double h[6];
+    sf_bspl6(a.knots, s, ell, x, h);
+    const int rows = a.m + 2;
+    const double* __restrict__ cf =
+        (a.coef_batched ? a.coef + (int64_t)b * a.nf * rows : a.coef) + (int64_t)(ell - 5) * rows;
+    double p = 1.0;
+    if (a.n_cheb > 0) p = sf_chebval(x / a.wave_max, P + a.off_cheb, a.n_cheb + 1, 1.0);  // transforms.py:302-304
+    auto rowval = [&](int r) {
+        double sp = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sp = sp + cf[(int64_t)j * rows + r] * h[j];
+        return a.n_cheb > 0 ? sp * p : sp;
+    };
+    const double mean = rowval(a.m), std = rowval(a.m + 1);
+    const double* __restrict__ wmu = a.mu + (int64_t)b * a.m;
+    double* __restrict__ Xb = a.X + (int64_t)b * a.m * a.ldx;
+    double flux = 0.0;
+    for (int k = 0; k < a.m; ++k) {
+        const double xk = rowval(k) * std;  // spectrum_model.py:312
+        Xb[(int64_t)k * a.ldx + i] = xk;
+        flux = flux + wmu[k] * xk;          // spectrum_model.py:313
+    }
+    a.flux[(int64_t)b * a.ldx + i] = flux + mean;
+}
+
+__device__ __forceinline__ double sf_block_sum(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+    return tot;
+}
+
+// One workgroup per walker: scale factor Omega (spectrum_model.py:316-329, transforms.py:265-268)
+__global__ __launch_bounds__(256) void k_scale(sf_scale_args a) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
+    const double norm = P[3];
+    double scale, lscale;
+    if (a.has_log_scale) {
+        lscale = P[2];
+        scale = exp(lscale) * norm;
+    } else {
+        const double* __restrict__ f = a.flux + (int64_t)b * a.ldx;
+        double sd = 0.0, sm = 0.0;
+        for (int i = tid; i + 1 < a.n; i += 256) {
+            const double d = a.wave[i + 1] - a.wave[i];
+            sd += d * (a.dflux[i + 1] + a.dflux[i]) / 2.0;
+            sm += d * (f[i + 1] * norm + f[i] * norm) / 2.0;
+        }
+        sd = sf_block_sum(sd, red);
+        sm = sf_block_sum(sm, red);
+        scale = sd / sm;
+        lscale = log(scale);
+        scale = scale * norm;
+    }
+    if (tid == 0) {
+        a.scale[b] = scale;
+        if (a.log_scale_out) a.log_scale_out[b] = lscale;
+    }
+}
+
+// Elementwise: rescale flux and X, residual, and Y = Lw^-1 X (or Lw^T X), zero padded.
+__global__ __launch_bounds__(256) void k_resid_y(sf_resid_args a) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= a.ldy) return;
+    double* __restrict__ Yb = a.Y ? a.Y + (int64_t)b * a.mpad * a.ldy : nullptr;
+    if (i >= a.n || (a.info && a.info[b] != 0)) {
+        if (Yb)
+            for (int k = 0; k < a.mpad; ++k) Yb[(int64_t)k * a.ldy + i] = 0.0;
+        if (i < a.ldx && a.resid) a.resid[(int64_t)b * a.ldx + i] = 0.0;
+        return;
+    }
+    const double sc = a.scale[b];
+    const double f = a.flux[(int64_t)b * a.ldx + i] * sc;  // transforms.py:231
+    if (a.flux_out) a.flux_out[(int64_t)b * a.n + i] = f;
+    if (a.resid) a.resid[(int64_t)b * a.ldx + i] = f - a.dflux[i];  // spectrum_model.py:402
+    const double* __restrict__ Xb = a.X + (int64_t)b * a.m * a.ldx;
+    double xs[SF_MAX_M];
+    for (int k = 0; k < a.m; ++k) {
+        xs[k] = Xb[(int64_t)k * a.ldx + i] * sc;
+        if (a.X_out) a.X_out[((int64_t)b * a.m + k) * a.n + i] = xs[k];
+    }
+    if (!Yb) return;
+    const double* __restrict__ Lw = a.Lw + (int64_t)b * a.m * a.m;
+    if (!a.use_sigma_w) {
+        // forward substitution Lw y = x  ->  y^T y = x^T Sigma_w^-1 x   (spectrum_model.py:334-335)
+        for (int k = 0; k < a.m; ++k) {
+            double v = xs[k];
+            for (int j = 0; j < k; ++j) v -= Lw[k * a.m + j] * xs[j];
+            xs[k] = v / Lw[k * a.m + k];
+            Yb[(int64_t)k * a.ldy + i] = xs[k];
+        }
+    } else {
+        // y = Lw^T x  ->  y^T y = x^T Sigma_w x   (the form printed in the paper / docs)
+        for (int k = 0; k < a.m; ++k) {
+            double v = 0.0;
+            for (int j = k; j < a.m; ++j) v += Lw[j * a.m + k] * xs[j];
+            Yb[(int64_t)k * a.ldy + i] = v;
+        }
+    }
+    for (int k = a.m; k < a.mpad; ++k) Yb[(int64_t)k * a.ldy + i] = 0.0;
+}
+
+// Chebyshev free function
+__global__ __launch_bounds__(256) void k_cheb_rows(const double* __restrict__ wave, int n, double wave_max,
+                                                   const double* __restrict__ flux, int rows,
+                                                   const double* __restrict__ coeffs, int ncoef,
+                                                   double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double p = sf_chebval(wave[i] / wave_max, coeffs + 1, ncoef, coeffs[0]);
+    for (int r = 0; r < rows; ++r) out[(int64_t)r * n + i] = flux[(int64_t)r * n + i] * p;
+}
+
+// ------------------------------------------------------------------------------------ emulator
+// One workgroup per parameter row.  emulator.py:376-388 with the constant v11 factored once:
+//   v11 = Lc Lc^T, alpha = v11^-1 w_hat, Linv = Lc^-1 (lower);  z = Linv v12;
+//   mu = v12^T alpha;  cov = v22 - z^T z.   Also returns Lw = chol(cov) for the rank-m factor.
+__global__ __launch_bounds__(256) void k_emulator(sf_emu_args a) {
+    extern __shared__ double esm[];
+    double* kv = esm;                 // m x M   v12 blocks
+    double* covs = kv + a.m * a.M;    // m x m
+    __shared__ int bad;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* __restrict__ P = a.params + (int64_t)b * a.pstride + a.off_grid;
+    const int mM = a.m * a.M;
+    if (tid == 0) {
+        bad = 0;
+        for (int d = 0; d < a.P; ++d)
+            if (P[d] < a.gmin[d] || P[d] > a.gmax[d]) bad = 1;  // emulator.py:377-378
+    }
+    __syncthreads();
+    if (bad) {
+        if (tid == 0 && a.info) a.info[b] = SF_INFO_OUT_OF_GRID;
+        return;
+    }
+    // v12 blocks: kernels.py:25-26 (cdist of X/l and Z/l, sqeuclidean)
+    for (int e = tid; e < mM; e += 256) {
+        const int i = e / a.M, j = e - i * a.M;
+        double d2 = 0.0;
+        for (int d = 0; d < a.P; ++d) {
+            const double l = a.lengthscales[i * a.P + d];
+            const double df = a.grid[j * a.P + d] / l - P[d] / l;
+            d2 = d2 + df * df;
+        }
+        kv[e] = a.variances[i] * exp(-0.5 * d2);
+    }
+    __syncthreads();
+    // z[r][i] = sum_j Linv[r][i*M + j] k_i[j]   (columns beyond r are zero in Linv)
+    double* __restrict__ z = a.zscratch + (int64_t)b * mM * a.m;
+    for (int e = tid; e < mM * a.m; e += 256) {
+        const int r = e / a.m, i = e - r * a.m;
+        const double* lr = a.Linv + (int64_t)r * mM + i * a.M;
+        const int jmax = min(a.M, r - i * a.M + 1);
+        double acc = 0.0;
+        for (int j = 0; j < jmax; ++j) acc += lr[j] * kv[i * a.M + j];
+        z[e] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < a.m * a.m; e += 256) {
+        const int i = e / a.m, j = e - i * a.m;
+        double acc = 0.0;
+        for (int r = 0; r < mM; ++r) acc += z[r * a.m + i] * z[r * a.m + j];
+        covs[e] = ((i == j) ? a.variances[i] : 0.0) - acc;  // v22 is diag(variances) at a single point
+    }
+    for (int i = tid; i < a.m; i += 256) {
+        double acc = 0.0;
+        for (int j = 0; j < a.M; ++j) acc += kv[i * a.M + j] * a.alpha[i * a.M + j];
+        a.mu[(int64_t)b * a.m + i] = acc;
+    }
+    __syncthreads();
+    if (a.cov)
+        for (int e = tid; e < a.m * a.m; e += 256) a.cov[(int64_t)b * a.m * a.m + e] = covs[e];
+    __syncthreads();
+    if (tid == 0 && a.Lw) {
+        // small dense Cholesky of Sigma_w (spectrum_model.py:334 cho_factor(weights_cov))
+        double* L = a.Lw + (int64_t)b * a.m * a.m;
+        int fail = 0;
+        for (int j = 0; j < a.m; ++j) {
+            double d = covs[j * a.m + j];
+            for (int k = 0; k < j; ++k) d -= L[j * a.m + k] * L[j * a.m + k];
+            if (!(d > 0.0)) { fail = 1; d = 1.0; }
+            const double dj = sqrt(d);
+            L[j * a.m + j] = dj;
+            for (int i = j + 1; i < a.m; ++i) {
+                double v = covs[i * a.m + j];
+                for (int k = 0; k < j; ++k) v -= L[i * a.m + k] * L[j * a.m + k];
+                L[i * a.m + j] = v / dj;
+            }
+            for (int i = 0; i < j; ++i) L[i * a.m + j] = 0.0;
+        }
+        if (fail && a.info) a.info[b] = SF_INFO_BAD_WEIGHT_COV;
+    }
+}
+
+// d_lnl = -(logdet + sqmah)/2, -inf where info != 0   (spectrum_model.py:405)
+__global__ void k_finish(int B, const double* __restrict__ logdet, const double* __restrict__ sqmah,
+                         const int* __restrict__ info, const int* __restrict__ info2,
+                         double* __restrict__ lnl, int* __restrict__ info_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int code = info ? info[b] : 0;
+    if (code == 0 && info2) code = info2[b];
+    double v = -(logdet[b] + sqmah[b]) / 2;
+    if (code != 0 || !(v == v)) v = -INFINITY;
+    lnl[b] = v;
+    if (info_out) info_out[b] = code;
+}
+
+// ------------------------------------------------------------------------------------ launchers
+static const size_t kLdsFftMax = 8192;  // complex points that fit the 160 KiB LDS (128 KiB)
+
+size_t sf_fft_scratch_bytes(int rows_total, int nf) {
+    return (size_t)nf > kLdsFftMax ? sizeof(double2) * (size_t)rows_total * nf : 0;
+}
+
+template <bool FWD>
+static int launch_broaden_t(const sf_broaden_args& a, hipStream_t s) {
+    const bool lds = (size_t)a.nf <= kLdsFftMax;
+    const size_t shm = lds ? sizeof(double2) * (size_t)a.nf : 0;
+    dim3 grid(a.rows, a.B);
+    if (lds) {
+        static bool set = false;
+        if (!set) {
+            SF_HIP(hipFuncSetAttribute((const void*)k_broaden<true, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            SF_HIP(hipFuncSetAttribute((const void*)k_broaden<false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            set = true;
+        }
+        hipLaunchKernelGGL((k_broaden<FWD, true>), grid, dim3(256), shm, s, a.in, a.spec, a.rows, a.nf, a.tw,
+                           a.dv, a.kind, a.params, a.pstride, a.poff, a.scalar_param, a.out, a.ob, a.orow,
+                           a.oelem, (double2*)nullptr, a.info);
+    } else {
+        if (!a.gscratch) {
+            sf_set_error("broaden: nf=%d needs a global FFT scratch buffer", a.nf);
+            return SF_ENOMEM;
+        }
+        hipLaunchKernelGGL((k_broaden<FWD, false>), grid, dim3(256), 0, s, a.in, a.spec, a.rows, a.nf, a.tw,
+                           a.dv, a.kind, a.params, a.pstride, a.poff, a.scalar_param, a.out, a.ob, a.orow,
+                           a.oelem, a.gscratch, a.info);
+    }
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_broaden(const sf_broaden_args& a, hipStream_t s) {
+    if (a.nf < 2 || (a.nf & (a.nf - 1)) || a.nf > 65536) {
+        sf_set_error("broaden: nf=%d must be a power of two in [2, 65536]", a.nf);
+        return SF_EINVAL;
+    }
+    return a.in ? launch_broaden_t<true>(a, s) : launch_broaden_t<false>(a, s);
+}
+
+int sf_launch_rfft_rows(const double* in, int rows, int nf, const double2* tw, double2* spec,
+                        double2* gscratch, hipStream_t s) {
+    const bool lds = (size_t)nf <= kLdsFftMax;
+    if (lds) {
+        static bool set = false;
+        if (!set) {
+            SF_HIP(hipFuncSetAttribute((const void*)k_rfft_rows<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            set = true;
+        }
+        hipLaunchKernelGGL(k_rfft_rows<true>, dim3(rows), dim3(256), sizeof(double2) * (size_t)nf, s, in, nf, tw,
+                           spec, (double2*)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_rfft_rows<false>, dim3(rows), dim3(256), 0, s, in, nf, tw, spec, gscratch);
+    }
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_spline_solve(double* data, int B, int rows, int64_t bstride, int64_t rstride,
+                           int64_t estride, int n, const double* Lf, const double* Uf, const double* rdiag,
+                           hipStream_t s) {
+    const int nsys = B * rows;
+    hipLaunchKernelGGL(k_spline_solve, dim3((nsys + 63) / 64), dim3(64), 0, s, data, nsys, rows, bstride,
+                       rstride, estride, n, Lf, Uf, rdiag);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_spline_eval(const double* coef, int rows, int ncoef, const double* t, const double* xq, int nq,
+                          double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_spline_eval, dim3((nq + 255) / 256), dim3(256), 0, s, coef, rows, ncoef, t, xq, nq,
+                       out);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_eval_rows(const sf_eval_args& a, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_rows, dim3((a.n + 255) / 256, B), dim3(256), 0, s, a);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_scale(const sf_scale_args& a, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_scale, dim3(B), dim3(256), 0, s, a);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_resid_y(const sf_resid_args& a, int B, hipStream_t s) {
+    if (a.m > SF_MAX_M) {
+        sf_set_error("at most %d eigenspectra are supported", SF_MAX_M);
+        return SF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_resid_y, dim3((a.ldy + 255) / 256, B), dim3(256), 0, s, a);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_cheb_rows(const double* wave, int n, double wave_max, const double* flux, int rows,
+                        const double* d_coeffs, int ncoef, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_cheb_rows, dim3((n + 255) / 256), dim3(256), 0, s, wave, n, wave_max, flux, rows,
+                       d_coeffs, ncoef, out);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_emulator(const sf_emu_args& a, int B, hipStream_t s) {
+    const size_t shm = sizeof(double) * ((size_t)a.m * a.M + (size_t)a.m * a.m);
+    if (shm > 64 * 1024) {
+        sf_set_error("emulator: m*M=%d too large for the LDS staging", a.m * a.M);
+        return SF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_emulator, dim3(B), dim3(256), shm, s, a);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_finish(int B, const double* logdet, const double* sqmah, const int* info, const int* info2,
+                     double* lnl, int* info_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_finish, dim3((B + 255) / 256), dim3(256), 0, s, B, logdet, sqmah, info, info2, lnl,
+                       info_out);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}

@@ -1,0 +1,143 @@
+"""
+Drop-in counterparts of ``Starfish.transforms`` (reference: Starfish/transforms.py).
+
+numpy arrays in, numpy arrays out, same names / argument meaning / exceptions; the arithmetic of
+``resample``, ``instrumental_broaden``, ``rotational_broaden`` and ``chebyshev_correct`` runs in the
+gfx950 HIP kernels behind the C-ABI (no CPU fallback: they raise ``StarfishAMDError`` without a GPU).
+Inside ``SpectrumModel`` these stages are fused per walker (``sf_transform_batch``); the free functions
+exist for API parity and stage-level tests.  ``doppler_shift`` / ``rescale`` are one-line scalar
+expressions kept on the host.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _device as D
+from . import _lib
+from .constants import c_kms
+from .utils import calculate_dv
+
+
+def _rows(flux):
+    flux = np.asarray(flux, dtype=np.float64)
+    one_d = flux.ndim == 1
+    return np.ascontiguousarray(np.atleast_2d(flux)), one_d
+
+
+def resample(wave, flux, new_wave):
+    """k=5 interpolating-spline resampling (Starfish/transforms.py:11-42)."""
+    new_wave = np.asarray(new_wave, dtype=np.float64)
+    if np.any(new_wave <= 0):
+        raise ValueError("Wavelengths must be positive")
+    lib = _lib.require_gpu()
+    wave = np.ascontiguousarray(np.asarray(wave, dtype=np.float64))
+    rows, one_d = _rows(flux)
+    dev = D.device_of()
+    n, nq = wave.shape[0], new_wave.shape[0]
+    d_flux = D.to_dev(rows, dev)
+    d_q = D.to_dev(new_wave, dev)
+    d_out = D.empty((rows.shape[0], nq), dev)
+    ws = D.workspace(lib.sf_resample_workspace_bytes(n, rows.shape[0]), dev)
+    rc = lib.sf_resample(
+        _lib.as_double_p(wave), n, D.ptr(d_flux), rows.shape[0], D.ptr(d_q), nq, D.ptr(d_out), D.ptr(ws),
+        ws.numel(), D.stream_ptr(dev),
+    )
+    _lib.check(rc, "sf_resample")
+    out = d_out.cpu().numpy()
+    return out[0] if one_d else out
+
+
+def _broaden(name, wave, flux, param):
+    lib = _lib.require_gpu()
+    rows, one_d = _rows(flux)
+    nf = rows.shape[-1]
+    dv = float(calculate_dv(wave))
+    dev = D.device_of()
+    d_flux = D.to_dev(rows, dev)
+    d_out = D.empty(rows.shape, dev)
+    ws = D.workspace(lib.sf_fft_workspace_bytes(rows.shape[0], nf), dev)
+    fn = getattr(lib, name)
+    rc = fn(D.ptr(d_flux), rows.shape[0], nf, dv, float(param), D.ptr(d_out), D.ptr(ws), ws.numel(),
+            D.stream_ptr(dev))
+    _lib.check(rc, name)
+    out = d_out.cpu().numpy()
+    return out[0] if one_d else out
+
+
+def instrumental_broaden(wave, flux, fwhm):
+    """Gaussian instrumental broadening in Fourier space (Starfish/transforms.py:45-90).
+    The last axis must have a power-of-two length (it always does on the model's log-lambda grid)."""
+    if fwhm < 0:
+        raise ValueError("FWHM must be non-negative")
+    return _broaden("sf_instrumental_broaden", wave, flux, fwhm)
+
+
+def rotational_broaden(wave, flux, vsini):
+    """Gray (2005) rotational broadening in Fourier space (Starfish/transforms.py:93-134)."""
+    if vsini <= 0:
+        raise ValueError("vsini must be positive")
+    return _broaden("sf_rotational_broaden", wave, flux, vsini)
+
+
+def doppler_shift(wave, vz):
+    """lambda * sqrt((c + vz) / (c - vz))  (Starfish/transforms.py:137-158)."""
+    dv = np.sqrt((c_kms + vz) / (c_kms - vz))
+    return np.asarray(wave) * dv
+
+
+def extinct(wave, flux, Av, Rv=3.1, law="ccm89"):
+    """Interstellar extinction (Starfish/transforms.py:161-206).  The reference delegates A_lambda to
+    the third-party ``extinction`` C extension, which is not part of the reference tree: parity is
+    unpinned, so only the identity case Av == 0 is provided."""
+    if law not in ["ccm89", "odonnell94", "calzetti00", "fitzpatrick99", "fm07"]:
+        raise ValueError("Invalid extinction law given")
+    if Rv <= 0:
+        raise ValueError("Rv must be positive")
+    if Av == 0:
+        return np.asarray(flux, dtype=np.float64) * 1.0
+    raise NotImplementedError("extinct(Av != 0) is not part of the MI355X hot path yet (parity unpinned)")
+
+
+def rescale(flux, scale):
+    """flux * Omega (Starfish/transforms.py:209-231)."""
+    scale = np.atleast_1d(scale)
+    if len(scale) > 1:
+        scale = scale[:, np.newaxis]
+    return flux * scale
+
+
+def _get_renorm_factor(wave, flux, reference_flux):
+    """Ratio of trapezoid integrals (Starfish/transforms.py:265-268)."""
+    wave = np.asarray(wave, dtype=np.float64)
+
+    def trapz(y):
+        y = np.asarray(y, dtype=np.float64)
+        return (np.diff(wave) * (y[..., 1:] + y[..., :-1]) / 2.0).sum(axis=-1)
+
+    return trapz(reference_flux) / trapz(flux)
+
+
+def renorm(wave, flux, reference_flux):
+    """Renormalise ``flux`` to the integrated ``reference_flux`` (Starfish/transforms.py:234-262)."""
+    return rescale(flux, _get_renorm_factor(wave, flux, reference_flux))
+
+
+def chebyshev_correct(wave, flux, coeffs):
+    """Multiply by a Chebyshev series in lambda / lambda_max (Starfish/transforms.py:271-304)."""
+    coeffs = np.ascontiguousarray(np.asarray(coeffs, dtype=np.float64))
+    if coeffs.ndim == 1 and coeffs[0] != 1:
+        raise ValueError("For single spectrum the linear Chebyshev coefficient (c[0]) must be 1")
+    lib = _lib.require_gpu()
+    wave = np.asarray(wave, dtype=np.float64)
+    rows, one_d = _rows(flux)
+    dev = D.device_of()
+    d_wave = D.to_dev(wave, dev)
+    d_flux = D.to_dev(rows, dev)
+    d_out = D.empty(rows.shape, dev)
+    rc = lib.sf_chebyshev_correct(
+        D.ptr(d_wave), wave.shape[0], float(wave.max()), D.ptr(d_flux), rows.shape[0],
+        _lib.as_double_p(coeffs), coeffs.shape[0], D.ptr(d_out), D.stream_ptr(dev),
+    )
+    _lib.check(rc, "sf_chebyshev_correct")
+    out = d_out.cpu().numpy()
+    return out[0] if one_d else out

@@ -1,0 +1,156 @@
+"""End-to-end parity of the batched HIP path (transform chain, fused fill, Cholesky, solve) against
+the CPU oracle and the reference-generated golden vectors.  Needs an MI355X: run with -m gpu."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import sf_oracle as O
+from starfish_amd import synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import gen_golden_cases as G  # noqa: E402
+from gpu_helpers import device_order, oracle_order, pack_rows  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+LNL_RTOL = 1e-8  # |dlnL| <= 1e-8 |lnL| + 1e-8  
+
+
+def close_lnl(got, want):
+    return abs(got - want) <= LNL_RTOL * abs(want) + 1e-8
+
+
+def small_params(o, name, factors):
+    from scipy.interpolate import LinearNDInterpolator
+
+    c = G.small_case_params(o, G.SMALL_CASES[name])
+    p = dict(grid=c["grid_params"])
+    for k in ("vz", "vsini", "log_scale", "cheb"):
+        if k in c:
+            p[k] = c[k]
+    if "global_cov" in c:
+        p["global_cov"] = (c["global_cov"]["log_amp"], c["global_cov"]["log_ls"])
+    if "local_cov" in c:
+        p["local_cov"] = [(k["mu"], k["log_amp"], k["log_sigma"]) for k in c["local_cov"]]
+    if G.SMALL_CASES[name].get("norm"):
+        p["norm"] = float(LinearNDInterpolator(o["grid_points"], factors, rescale=True)(np.asarray(p["grid"])))
+    return p
+
+
+@pytest.fixture(scope="module")
+def small():
+    o = synth.make_order(N=256, m=4, seed=5)
+    oo = oracle_order(o)
+    return o, oo, device_order(oo)
+
+
+@pytest.mark.parametrize("name", list(G.SMALL_CASES))
+def test_small_model_cases_vs_reference(small, name):
+    o, oo, do = small
+    g = load_golden("model_small.npz")
+    p = small_params(o, name, g["factors"])
+    md, rows = pack_rows(do, [p])
+    ref = g[f"{name}_lnl"]
+
+    tr = do.transform(md, rows)
+    assert tr["info"][0] == 0
+    f_or, c_or, _ = O.forward_model(oo, p)
+    np.testing.assert_allclose(tr["flux"][0], g[f"{name}_flux"], rtol=0, atol=1e-10 * np.abs(f_or).max())
+    assert abs(tr["log_scale"][0] - ref[3]) <= 1e-10 * max(1.0, abs(ref[3]))
+    np.testing.assert_allclose(tr["resid"][0], g[f"{name}_flux"] - oo.flux, rtol=0, atol=1e-10)
+
+    fw = do.forward(md, rows)
+    atol = 1e-11 * np.abs(c_or).max()
+    if f"{name}_cov" in g:
+        np.testing.assert_allclose(fw["cov"][0], g[f"{name}_cov"], rtol=1e-10, atol=atol)
+    else:
+        np.testing.assert_allclose(fw["cov"][0][G.COV_ROWS], g[f"{name}_covrows"], rtol=1e-10, atol=atol)
+        np.testing.assert_allclose(fw["cov"][0].diagonal(), g[f"{name}_diag"], rtol=1e-10)
+    np.testing.assert_allclose(fw["cov"][0], fw["cov"][0].T, rtol=0, atol=0)
+
+    ll = do.loglike(md, rows)
+    assert ll["info"][0] == 0
+    assert close_lnl(ll["lnl"][0], ref[0])
+    assert abs(ll["logdet"][0] - ref[1]) <= 1e-10 * abs(ref[1])
+    assert abs(ll["sqmah"][0] - ref[2]) <= 1e-8 * abs(ref[2])
+
+
+def test_batch_matches_oracle_and_reference_n1024():
+    g = load_golden("model_large.npz")
+    o = synth.make_order(N=1024)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    P = synth.walker_ball(o, B=128)
+    plist = [synth.vector_to_oracle_params(p) for p in P[:16]]
+    md, rows = pack_rows(do, plist)
+    out = do.loglike(md, rows, want_resid=True)
+    assert (out["info"] == 0).all()
+    for b in range(8):  # from the real reference
+        assert close_lnl(out["lnl"][b], g["n1024_batch_lnl"][b])
+    for b in (8, 15):  # beyond the fixture: the pinned oracle
+        want, logdet, sqmah, R = O.log_likelihood(oo, plist[b], return_parts=True)
+        assert close_lnl(out["lnl"][b], want)
+        np.testing.assert_allclose(out["resid"][b], R, rtol=0, atol=1e-10)
+    # centre point: the survey's known answer
+    md, rows = pack_rows(do, [synth.vector_to_oracle_params(synth.centre_vector(o))])
+    assert abs(do.loglike(md, rows)["lnl"][0] - 4124.8909586559) < 1e-6
+    # chunked evaluation gives identical numbers
+    md, rows = pack_rows(do, plist)
+    out2 = do.loglike(md, rows, max_chunk=5)
+    np.testing.assert_array_equal(out2["lnl"], out["lnl"])
+
+
+def test_ragged_size_n3000_and_sampled_covariance():
+    g = load_golden("model_large.npz")
+    o = synth.make_order(N=3000)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    P = g["n3000_batch_P"]
+    plist = [synth.vector_to_oracle_params(synth.centre_vector(o))] + [synth.vector_to_oracle_params(p) for p in P]
+    md, rows = pack_rows(do, plist)
+    out = do.loglike(md, rows)
+    assert close_lnl(out["lnl"][0], g["n3000_lnl"][0])
+    for b in range(len(P)):
+        assert close_lnl(out["lnl"][1 + b], g["n3000_batch_lnl"][b])
+    fw = do.forward(md, rows[:1])
+    cov = fw["cov"][0]
+    np.testing.assert_allclose(fw["flux"][0], g["n3000_flux"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(cov.diagonal(), g["n3000_diag"], rtol=1e-10)
+    np.testing.assert_allclose(cov[g["n3000_ii"], g["n3000_jj"]], g["n3000_vals"], rtol=1e-10,
+                               atol=1e-11 * np.abs(g["n3000_diag"]).max())
+    np.testing.assert_allclose(cov.sum(axis=1), g["n3000_rowsum"], rtol=1e-9, atol=1e-12)
+
+
+def test_out_of_grid_and_bad_vsini_are_flagged_not_fatal():
+    o = synth.make_order(N=256, m=4, seed=5)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    good = synth.vector_to_oracle_params(synth.centre_vector(o))
+    bad_grid = dict(good, grid=[5990.0, 4.2, -0.3])
+    bad_vsini = dict(good, vsini=-1.0)
+    md, rows = pack_rows(do, [good, bad_grid, bad_vsini, good])
+    out = do.loglike(md, rows)
+    assert out["info"].tolist() == [0, -1, -2, 0]
+    assert np.isfinite(out["lnl"][0]) and out["lnl"][0] == out["lnl"][3]
+    assert out["lnl"][1] == -np.inf and out["lnl"][2] == -np.inf
+
+
+def test_wasp14_order_plumbing():
+    """BASELINE config 1: bundled WASP14 order 23 (masked, N = 1932) against the reference value."""
+    d = load_golden("wasp14_order23.npz")
+    g = load_golden("model_wasp14.npz")
+    mask = d["mask"]
+    oo = O.OracleOrder(d["wave"][mask], d["flux"][mask], d["sigma"][mask], g["emu_wl"], g["eigenspectra"],
+                       g["flux_mean"], g["flux_std"], g["grid_points"], g["w_hat"])
+    do = device_order(oo)
+    vec = g["vector"]
+    assert tuple(g["labels"]) == synth.LABELS
+    p = synth.vector_to_oracle_params(vec)
+    md, rows = pack_rows(do, [p])
+    out = do.loglike(md, rows)
+    assert out["info"][0] == 0
+    assert close_lnl(out["lnl"][0], g["lnl"][0])
+    assert close_lnl(O.log_likelihood(oo, p), g["lnl"][0])

@@ -1,0 +1,161 @@
+"""Stage-level parity of the HIP kernels (through the C-ABI) against the golden vectors produced by
+the reference and against the CPU oracle.  Needs an MI355X: run with -m gpu."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from starfish_amd import _lib
+
+    return _lib.require_gpu()
+
+
+@pytest.mark.parametrize("N", [64, 200])
+def test_covariance_kernels_vs_reference(gpu, N):
+    from starfish_amd.models.kernels import global_covariance_matrix, local_covariance_matrix
+
+    g = load_golden("kernels.npz")
+    wave = g[f"wave_{N}"]
+    for i, (a, l) in enumerate(g[f"g_params_{N}"]):
+        got = global_covariance_matrix(wave, a, l)
+        np.testing.assert_allclose(got, g[f"g_{N}_{i}"], rtol=1e-13, atol=1e-300)
+    for i, (a, mu, s) in enumerate(g[f"l_params_{N}"]):
+        got = local_covariance_matrix(wave, a, mu, s)
+        np.testing.assert_allclose(got, g[f"l_{N}_{i}"], rtol=1e-13, atol=1e-300)
+
+
+@pytest.mark.parametrize("tag", ["s", "l"])
+def test_transforms_vs_reference(gpu, tag):
+    from starfish_amd import transforms as T
+
+    g = load_golden("transforms.npz")
+    grid, wave, flux = g[f"{tag}_grid"], g[f"{tag}_wave"], g[f"{tag}_flux"]
+    scale = np.abs(flux).max()
+    for i, v in enumerate(g[f"{tag}_vsini"]):
+        got = T.rotational_broaden(grid, flux, v)
+        assert np.abs(got - g[f"{tag}_rot_{i}"]).max() <= 1e-10 * scale
+    for i, f in enumerate(g[f"{tag}_fwhm"]):
+        got = T.instrumental_broaden(grid, flux, f)
+        assert np.abs(got - g[f"{tag}_inst_{i}"]).max() <= 1e-10 * scale
+    for i, vz in enumerate(g[f"{tag}_vz"]):
+        sh = T.doppler_shift(grid, vz)
+        np.testing.assert_array_equal(sh, g[f"{tag}_dop_{i}"])
+        got = T.resample(sh, flux, g[f"{tag}_resq_{i}"])
+        assert np.abs(got - g[f"{tag}_res_{i}"]).max() <= 1e-10 * scale
+    got = T.chebyshev_correct(wave, g[f"{tag}_cheb_in"], g[f"{tag}_cheb_c"])
+    np.testing.assert_allclose(got, g[f"{tag}_cheb"], rtol=1e-14)
+    # 1-D forms
+    got1 = T.rotational_broaden(grid, flux[0], g[f"{tag}_vsini"][0])
+    assert got1.shape == flux[0].shape
+    assert np.abs(got1 - g[f"{tag}_rot_0"][0]).max() <= 1e-10 * scale
+
+
+def test_resample_irregular_grid(gpu):
+    from starfish_amd import transforms as T
+
+    g = load_golden("transforms.npz")
+    got = T.resample(g["irr_x"], g["irr_y"], g["irr_q"])
+    assert np.abs(got - g["irr_out"]).max() <= 1e-11
+
+
+def test_transform_argument_errors(gpu):
+    from starfish_amd import transforms as T
+
+    w = np.linspace(5000, 5010, 64)
+    f = np.ones(64)
+    with pytest.raises(ValueError):
+        T.rotational_broaden(w, f, 0.0)
+    with pytest.raises(ValueError):
+        T.rotational_broaden(w, f, -3.0)
+    with pytest.raises(ValueError):
+        T.instrumental_broaden(w, f, -1.0)
+    with pytest.raises(ValueError):
+        T.resample(w, f, np.array([-1.0, 5001.0]))
+    with pytest.raises(ValueError):
+        T.chebyshev_correct(w, f, [0.9, 0.1])
+    np.testing.assert_allclose(T.instrumental_broaden(w, f, 0.0), f, atol=1e-14)
+
+
+@pytest.mark.parametrize("n,batch", [(64, 3), (256, 5), (1024, 2), (1088, 2)])
+def test_potrf_logdet_sqmah_random_spd(gpu, n, batch):
+    import torch
+    from starfish_amd import _device as D, _lib
+
+    rng = np.random.default_rng(n)
+    dev = D.device_of()
+    lda = n + 16
+    A = np.zeros((batch, n, lda))
+    R = rng.standard_normal((batch, n))
+    want_ld, want_sq = [], []
+    for b in range(batch):
+        G = rng.standard_normal((n, n))
+        S = G @ G.T / n + np.diag(rng.uniform(0.5, 2.0, n))
+        A[b, :, :n] = S
+        L = np.linalg.cholesky(S)
+        z = np.linalg.solve(L, R[b])
+        want_ld.append(2 * np.log(np.diag(L)).sum())
+        want_sq.append(z @ z)
+    dA = D.to_dev(A, dev)
+    dR = D.to_dev(R, dev)
+    info = D.empty((batch,), dev, torch.int32)
+    ld = D.empty((batch,), dev)
+    sq = D.empty((batch,), dev)
+    ws = D.workspace(gpu.sf_potrf_workspace_bytes(n, batch), dev)
+    s = D.stream_ptr(dev)
+    _lib.check(gpu.sf_potrf_batch(D.ptr(dA), n, lda, n * lda, batch, D.ptr(info), D.ptr(ws), ws.numel(), s))
+    _lib.check(gpu.sf_logdet_sqmah_batch(D.ptr(dA), n, lda, n * lda, batch, D.ptr(dR), n, D.ptr(ws),
+                                         ws.numel(), D.ptr(ld), D.ptr(sq), s))
+    assert (info.cpu().numpy() == 0).all()
+    np.testing.assert_allclose(ld.cpu().numpy(), want_ld, rtol=1e-12)
+    np.testing.assert_allclose(sq.cpu().numpy(), want_sq, rtol=1e-11)
+    Lgpu = np.tril(dA.cpu().numpy()[0, :, :n])
+    np.testing.assert_allclose(Lgpu, np.linalg.cholesky(A[0, :, :n]), rtol=0, atol=1e-12)
+
+
+def test_potrf_reports_non_positive_pivot(gpu):
+    import torch
+    from starfish_amd import _device as D, _lib
+
+    n, lda = 128, 144
+    A = np.zeros((2, n, lda))
+    A[0, :, :n] = np.eye(n)
+    A[1, :, :n] = np.eye(n)
+    A[1, 70, 70] = -1.0
+    dev = D.device_of()
+    dA = D.to_dev(A, dev)
+    info = D.empty((2,), dev, torch.int32)
+    ws = D.workspace(gpu.sf_potrf_workspace_bytes(n, 2), dev)
+    _lib.check(gpu.sf_potrf_batch(D.ptr(dA), n, lda, n * lda, 2, D.ptr(info), D.ptr(ws), ws.numel(),
+                                  D.stream_ptr(dev)))
+    assert info.cpu().numpy().tolist() == [0, 71]
+
+
+@pytest.mark.parametrize("tag,m", [("a", 8), ("b", 4)])
+def test_emulator_query_vs_reference(gpu, tag, m):
+    from starfish_amd import synth
+    from starfish_amd import _device as D
+
+    g = load_golden("emulator.npz")
+    o = synth.make_order(N=256, m=m, seed=3)
+    do = D.DeviceOrder(
+        np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros((0, 0)), o["grid_points"],
+        g[f"{tag}_variances"], g[f"{tag}_lengthscales"], g[f"{tag}_v11"], o["w_hat"],
+    )
+    q = g[f"{tag}_queries"]
+    mu, cov, info = do.emulator_query(q)
+    assert (info == 0).all()
+    for i in range(len(q)):
+        np.testing.assert_allclose(mu[i], g[f"{tag}_mu_{i}"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(cov[i], g[f"{tag}_cov_{i}"], rtol=1e-9, atol=1e-9)
+    _, _, info = do.emulator_query([[5999.0, 4.2, -0.3], [6050.0, 4.2, 0.01]])
+    assert info.tolist() == [-1, -1]
