@@ -129,6 +129,10 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C starfish_amd/csrc`.  There is no CPU fallback."
         )
+    # torch ships its own libamdhip64.so.7 (same SONAME as /opt/rocm's): load torch FIRST so that the
+    # process holds exactly one HIP runtime, shared by torch's allocator/streams and these kernels.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
