@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark of the log-likelihood hot path (BASELINE.json):
+log-likelihood evals/sec on a synthetic 4096-pixel order, batch = 128 walkers, fp64, per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = one pass of the whole hot path (emulator query, transform chain, fused covariance fill,
+batched Cholesky, solve) over one batch of 128 walkers, parameters and static order data already
+resident in HBM.  Every rank works on its own batch of 128 walkers (weak scaling, no data-path
+collective: the walker x order units are independent); `value` = evals of all ranks / max-over-ranks
+time.  Rank 0 prints ONE JSON line which also carries
+  roofline     -- the dominant kernel (k_gemm_nt, the fp64 MFMA trailing update of the Cholesky):
+                  algorithmic flops of its launches / their HIP-event time on the launch stream
+  cpu_baseline -- the CPU oracle (numpy/scipy restatement == the reference's algorithm) timed on the
+                  host cores over a bounded sample of the same walkers (N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (datasheet)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--npix", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--cpu-sample", type=int, default=8, help="walkers timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from gpu_helpers import device_order, oracle_order, pack_rows
+    from starfish_amd import _device as D
+    from starfish_amd import synth
+
+    N, B = args.npix, args.batch
+    order = synth.make_order(N=N)
+    oo = oracle_order(order)  # static arrays (bulk_fluxes, v11) shared by the HIP path and the oracle
+    do = device_order(oo)
+    P = synth.walker_ball(order, B=B, seed=1 + rank)  # each rank owns a different block of walkers
+    plist = [synth.vector_to_oracle_params(p) for p in P]
+    md, rows = pack_rows(do, plist)
+    P_dev = D.to_dev(rows, do.dev)
+    lnl = D.empty((B,), do.dev)
+    info = D.empty((B,), do.dev, torch.int32)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        do.loglike_device(md, P_dev, lnl, info)
+    torch.cuda.synchronize()
+    do.lib.sf_profile_read(None, None, None, None)
+    do.lib.sf_profile_enable(1)  # HIP events on the launch stream around every k_gemm_nt launch
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        do.loglike_device(md, P_dev, lnl, info)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    do.lib.sf_profile_enable(0)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=do.dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    ms = (C.c_double * 5)()
+    gflops, glaunch, gcalls = C.c_double(), C.c_long(), C.c_long()
+    do.lib.sf_profile_read(ms, C.byref(gflops), C.byref(glaunch), C.byref(gcalls))
+    lnl_host = lnl.cpu().numpy()
+    info_host = info.cpu().numpy()
+    assert (info_host == 0).all(), info_host
+    assert np.isfinite(lnl_host).all()
+
+    if rank == 0:
+        gemm_s = ms[2] * 1e-3
+        achieved = gflops.value / gemm_s / 1e12 if gemm_s > 0 else 0.0
+        flops_eval = N**3 / 3 + 2 * 8 * N**2 + N**2
+        out = {
+            "metric": "log-likelihood evals/sec, 4096-pixel order, batch=128 walkers",
+            "value": B * world * args.steps / dt_max,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"cfg2: synthetic single order N_pix={N}, 8 eigenspectra, M=27, N_f={do.nf}, "
+                f"1 global + 1 local kernel, all 13 parameters thawed, batch={B} walkers per GPU",
+                "global_batch": B * world,
+                "parallelism": f"walker-sharded x{world}, no collective",
+            },
+            "whole_path_tflops": B * world * args.steps * flops_eval / dt_max / 1e12,
+            "roofline": {
+                "kernel": "k_gemm_nt (v_mfma_f64_16x16x4_f64 trailing update of the batched Cholesky)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "launches": int(glaunch.value),
+                "avg_launch_ms": ms[2] / max(1, glaunch.value),
+                "algorithmic_flops_per_launch": gflops.value / max(1, glaunch.value),
+            },
+            "stage_ms_per_step": {
+                k: v / max(1, args.steps)
+                for k, v in zip(["transforms", "fill", "gemm", "potrf_total", "solve"], ms)
+            },
+        }
+        if world == 1 and args.cpu_sample > 0:
+            from oracle import sf_oracle as O
+
+            k = min(args.cpu_sample, B)
+            O.log_likelihood(oo, plist[0])  # warm the BLAS threads
+            tc = time.perf_counter()
+            want = np.array([O.log_likelihood(oo, p) for p in plist[:k]])
+            tcpu = time.perf_counter() - tc
+            rel = np.abs(lnl_host[:k] - want) / np.abs(want)
+            try:
+                from threadpoolctl import threadpool_info
+
+                nthreads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+            except Exception:
+                nthreads = os.cpu_count()
+            out["cpu_baseline"] = {
+                "value": k / tcpu,
+                "unit": "evals/s",
+                "cores": int(nthreads),
+                "kind": "port",
+                "sample": f"first {k} walkers of the same batch through oracle/sf_oracle.py "
+                f"(numpy/scipy, default BLAS threads; host has {os.cpu_count()} logical CPUs)",
+                "max_rel_dlnl_vs_gpu": float(rel.max()),
+            }
+            assert rel.max() < 1e-8, rel
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,265 @@
+"""
+Query side of the Bayesian spectral emulator (reference: Starfish/emulator/emulator.py).
+
+Kept: the constructor and its attributes, ``__call__`` (GP conditional mean / covariance of the PCA
+weights), ``bulk_fluxes``, ``norm_factor``, hyper-parameter accessors, ``load`` / ``save``.
+``__call__`` runs in the ``k_emulator`` HIP kernel through ``sf_emulator_query_batch``; the constant
+``v11`` is factored once per hyper-parameter set instead of on every call (emulator.py:387-388).
+Out of scope (one-time offline set-up): ``from_grid``, ``train``, plotting.
+"""
+import logging
+import os
+import warnings
+
+import numpy as np
+
+from .. import _device as D
+from ..utils import calculate_dv
+from ._utils import get_phi_squared
+from .kernels import batch_kernel
+
+log = logging.getLogger(__name__)
+
+
+class Emulator:
+    def __init__(
+        self,
+        grid_points,
+        param_names,
+        wavelength,
+        weights,
+        eigenspectra,
+        w_hat,
+        flux_mean,
+        flux_std,
+        factors,
+        lambda_xi=1.0,
+        variances=None,
+        lengthscales=None,
+        name=None,
+    ):
+        self.log = logging.getLogger(self.__class__.__name__)
+        self.grid_points = np.asarray(grid_points, dtype=np.float64)
+        self.param_names = param_names
+        self.wl = np.asarray(wavelength, dtype=np.float64)
+        self.weights = weights
+        self.eigenspectra = np.asarray(eigenspectra, dtype=np.float64)
+        self.flux_mean = np.asarray(flux_mean, dtype=np.float64)
+        self.flux_std = np.asarray(flux_std, dtype=np.float64)
+        self.factors = np.asarray(factors, dtype=np.float64)
+        self._factor_interpolator = None
+
+        self.dv = calculate_dv(self.wl)
+        self.ncomps = self.eigenspectra.shape[0]
+
+        self.hyperparams = {}
+        self.name = name
+        self.lambda_xi = lambda_xi
+        self.variances = variances if variances is not None else 1e4 * np.ones(self.ncomps)
+
+        unique = [sorted(np.unique(col)) for col in self.grid_points.T]
+        self._grid_sep = np.array([np.diff(u).max() for u in unique])
+        if lengthscales is None:
+            lengthscales = np.tile(3 * self._grid_sep, (self.ncomps, 1))
+        self.lengthscales = lengthscales
+
+        self.min_params = self.grid_points.min(axis=0)
+        self.max_params = self.grid_points.max(axis=0)
+
+        self.iPhiPhi = np.linalg.inv(get_phi_squared(self.eigenspectra, self.grid_points.shape[0]))
+        self.w_hat = np.asarray(w_hat, dtype=np.float64)
+        self._trained = False
+        self._device = None
+        self._refresh_v11()
+
+    # ----------------------------------------------------------------- hyper-parameters
+    def _refresh_v11(self):
+        # emulator.py:126-128 / 569-571
+        self.v11 = self.iPhiPhi / self.lambda_xi + batch_kernel(
+            self.grid_points, self.grid_points, self.variances, self.lengthscales
+        )
+        self._device = None  # the device-side factor of v11 is rebuilt lazily
+
+    @property
+    def lambda_xi(self):
+        return np.exp(self.hyperparams["log_lambda_xi"])
+
+    @lambda_xi.setter
+    def lambda_xi(self, value):
+        self.hyperparams["log_lambda_xi"] = np.log(value)
+
+    @property
+    def variances(self):
+        vals = [v for k, v in self.hyperparams.items() if k.startswith("log_variance:")]
+        return np.exp(vals)
+
+    @variances.setter
+    def variances(self, values):
+        for i, value in enumerate(values):
+            self.hyperparams[f"log_variance:{i}"] = np.log(value)
+
+    @property
+    def lengthscales(self):
+        vals = [v for k, v in self.hyperparams.items() if k.startswith("log_lengthscale:")]
+        return np.exp(vals).reshape(self.ncomps, -1)
+
+    @lengthscales.setter
+    def lengthscales(self, values):
+        for i, value in enumerate(values):
+            for j, ls in enumerate(value):
+                self.hyperparams[f"log_lengthscale:{i}:{j}"] = np.log(ls)
+
+    def __getitem__(self, key):
+        return self.hyperparams[key]
+
+    def get_param_dict(self):
+        return self.hyperparams
+
+    def set_param_dict(self, params):
+        for key, val in params.items():
+            if key in self.hyperparams:
+                self.hyperparams[key] = val
+        self._refresh_v11()
+
+    def get_param_vector(self):
+        return np.array(list(self.get_param_dict().values()))
+
+    def set_param_vector(self, params):
+        parameters = self.get_param_dict()
+        if len(params) != len(parameters):
+            raise ValueError("params must match length of parameters (get_param_vector())")
+        self.set_param_dict(dict(zip(parameters.keys(), params)))
+
+    # ----------------------------------------------------------------- query
+    def _dev(self):
+        if self._device is None:
+            z = np.zeros(0)
+            self._device = D.DeviceOrder(
+                z, z, z, z, np.zeros((0, 0)), self.grid_points, self.variances, self.lengthscales,
+                self.v11, self.w_hat,
+            )
+        return self._device
+
+    def __call__(self, params, full_cov=True, reinterpret_batch=False):
+        """mu, cov of the PCA weights at ``params`` (Starfish/emulator/emulator.py:330-394).
+
+        A single parameter vector gives ``mu (m,)`` and ``cov (m, m)``.  With
+        ``reinterpret_batch=True`` a list of vectors returns per-point means ``(B, m)`` and variances
+        ``(B, m)``.  (The reference's joint covariance across several query points,
+        ``full_cov=True`` with more than one point, is not on the model path and is not provided.)"""
+        params = np.atleast_2d(np.asarray(params, dtype=np.float64))
+        if full_cov and reinterpret_batch:
+            raise ValueError("Cannot reshape the full_covariance matrix for many parameters.")
+        if not self._trained:
+            warnings.warn(
+                "This emulator has not been trained and therefore is not reliable. call "
+                "emulator.train() to train."
+            )
+        if np.any(params < self.min_params) or np.any(params > self.max_params):
+            raise ValueError("Querying emulator outside of original parameter range.")
+        if params.shape[0] > 1 and not reinterpret_batch:
+            raise NotImplementedError(
+                "joint covariance across several query points is not provided; use reinterpret_batch=True"
+            )
+        mu, cov, info = self._dev().emulator_query(params)
+        if np.any(info != 0):
+            raise ValueError(D.INFO_MESSAGES.get(int(info[info != 0][0]), "emulator query failed"))
+        if reinterpret_batch:
+            return mu.squeeze(), np.diagonal(cov, axis1=1, axis2=2).squeeze()
+        mu, cov = mu[0], cov[0]
+        if not full_cov:
+            cov = np.diag(cov)
+        return mu, cov
+
+    @property
+    def bulk_fluxes(self):
+        """vstack of eigenspectra, flux_mean, flux_std (Starfish/emulator/emulator.py:396-402)."""
+        return np.vstack([self.eigenspectra, self.flux_mean, self.flux_std])
+
+    def norm_factor(self, params):
+        """Linear interpolation of the library normalisation factors
+        (Starfish/emulator/emulator.py:429-444; host-side, only used when ``norm=True``)."""
+        if self._factor_interpolator is None:
+            from scipy.interpolate import LinearNDInterpolator
+
+            self._factor_interpolator = LinearNDInterpolator(self.grid_points, self.factors, rescale=True)
+        return self._factor_interpolator(np.asarray(params))
+
+    def get_index(self, params):
+        params = np.atleast_2d(params)
+        marks = np.abs(self.grid_points - np.expand_dims(params, 1)).sum(axis=-1)
+        return marks.argmin(axis=1).squeeze()
+
+    # ----------------------------------------------------------------- persistence
+    @classmethod
+    def load(cls, filename):
+        """HDF5 layout of Starfish/emulator/emulator.py:188-231 (needs h5py)."""
+        try:
+            import h5py
+        except ImportError as e:  # pragma: no cover - h5py is absent on the GPU box
+            raise ImportError("Emulator.load needs h5py; construct the Emulator from arrays instead") from e
+        filename = os.path.expandvars(filename)
+        with h5py.File(filename, "r") as base:
+            kw = dict(
+                grid_points=base["grid_points"][:],
+                param_names=base["grid_points"].attrs["names"],
+                wavelength=base["wavelength"][:],
+                weights=base["weights"][:],
+                eigenspectra=base["eigenspectra"][:],
+                flux_mean=base["flux_mean"][:],
+                flux_std=base["flux_std"][:],
+                w_hat=base["w_hat"][:],
+                factors=base["factors"][:],
+                lambda_xi=base["hyperparameters"]["lambda_xi"][()],
+                variances=base["hyperparameters"]["variances"][:],
+                lengthscales=base["hyperparameters"]["lengthscales"][:],
+            )
+            trained = base.attrs["trained"]
+            name = base.attrs["name"] if "name" in base.attrs else ".".join(filename.split(".")[:-1])
+        emu = cls(name=name, **kw)
+        emu._trained = trained
+        return emu
+
+    def save(self, filename):
+        """HDF5 layout of Starfish/emulator/emulator.py:233-270 (needs h5py)."""
+        try:
+            import h5py
+        except ImportError as e:  # pragma: no cover
+            raise ImportError("Emulator.save needs h5py") from e
+        filename = os.path.expandvars(filename)
+        with h5py.File(filename, "w") as base:
+            gp = base.create_dataset("grid_points", data=self.grid_points, compression=9)
+            gp.attrs["names"] = self.param_names
+            base.create_dataset("wavelength", data=self.wl, compression=9)
+            base.create_dataset("weights", data=self.weights, compression=9)
+            base.create_dataset("eigenspectra", data=self.eigenspectra, compression=9)
+            base.create_dataset("flux_mean", data=self.flux_mean, compression=9)
+            base.create_dataset("flux_std", data=self.flux_std, compression=9)
+            base.create_dataset("w_hat", data=self.w_hat, compression=9)
+            base.attrs["trained"] = self._trained
+            if self.name is not None:
+                base.attrs["name"] = self.name
+            base.create_dataset("factors", data=self.factors, compression=9)
+            hp = base.create_group("hyperparameters")
+            hp.create_dataset("lambda_xi", data=self.lambda_xi)
+            hp.create_dataset("variances", data=self.variances, compression=9)
+            hp.create_dataset("lengthscales", data=self.lengthscales, compression=9)
+
+    @classmethod
+    def from_grid(cls, grid, **pca_kwargs):
+        raise NotImplementedError("Emulator.from_grid (PCA of a spectral library) is offline set-up, out of scope")
+
+    def train(self, **opt_kwargs):
+        raise NotImplementedError("Emulator.train is offline set-up, out of scope for the MI355X hot path")
+
+    def __repr__(self):
+        out = "Emulator\n" + "-" * 8 + "\n"
+        if self.name is not None:
+            out += f"Name: {self.name}\n"
+        out += f"Trained: {self._trained}\n"
+        out += f"lambda_xi: {self.lambda_xi:.3f}\n"
+        out += "Variances:\n" + "\n".join(f"\t{v:.2f}" for v in self.variances)
+        out += "\nLengthscales:\n" + "\n".join(
+            "\t[ " + " ".join(f"{l:.2f} " for l in ls) + "]" for ls in self.lengthscales
+        )
+        return out + "\n"

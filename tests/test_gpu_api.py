@@ -1,0 +1,163 @@
+"""The drop-in Python surface (SpectrumModel / Emulator / EchelleModel) on the GPU against values
+produced by the real reference (golden fixtures) and against the oracle.  Run with -m gpu."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from starfish_amd import Spectrum, synth
+from starfish_amd.emulator import Emulator
+from starfish_amd.models import EchelleModel, SpectrumModel
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import gen_golden_cases as G  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def build(o, params=None, norm=False, factors=None):
+    emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"],
+                   o["w_hat"], o["flux_mean"], o["flux_std"], o["factors"] if factors is None else factors)
+    emu._trained = True
+    data = Spectrum(o["wave"], o["flux"], sigmas=o["sigma"])
+    c = dict(synth.centre_params(o)) if params is None else dict(params)
+    gp = c.pop("grid_params")
+    return SpectrumModel(emu, data, grid_params=gp, norm=norm, **c)
+
+
+def close(a, b):
+    return abs(a - b) <= 1e-8 * abs(b) + 1e-8
+
+
+@pytest.mark.parametrize("name", list(G.SMALL_CASES))
+def test_spectrum_model_cases_vs_reference(name):
+    g = load_golden("model_small.npz")
+    o = synth.make_order(N=256, m=4, seed=5)
+    spec = G.SMALL_CASES[name]
+    m = build(o, G.small_case_params(o, spec), norm=spec.get("norm", False), factors=g["factors"])
+    assert tuple(g[f"{name}_labels"]) == m.labels
+    np.testing.assert_allclose(m.get_param_vector(), g[f"{name}_vector"])
+    np.testing.assert_allclose(m.min_dv_wave, g["min_dv_wave"], rtol=1e-15)
+    np.testing.assert_allclose(m.bulk_fluxes, g["bulk_fluxes"], rtol=0, atol=1e-12)
+    ref = g[f"{name}_lnl"]
+    assert close(m.log_likelihood(), ref[0])
+    assert abs(m._log_scale - ref[3]) <= 1e-10 * max(1, abs(ref[3]))
+    assert len(m.residuals) == 1 and m._lnprob is not None
+    flux, cov = m()
+    np.testing.assert_allclose(flux, g[f"{name}_flux"], rtol=0, atol=1e-10)
+    assert cov.shape == (256, 256)
+
+
+def test_frozen_covariance_cache_semantics():
+    g = load_golden("model_small.npz")
+    o = synth.make_order(N=256, m=4, seed=5)
+    m = build(o, factors=g["factors"])
+    m.freeze("global_cov")
+    assert m._glob_cov is None
+    a = m.log_likelihood()
+    assert m._glob_cov is not None
+    m["global_cov:log_amp"] = -7.0  # the cached (frozen) kernel must still be used
+    b = m.log_likelihood()
+    m.thaw("global_cov")
+    c = m.log_likelihood()
+    want = g["frozen_glob"]
+    assert close(a, want[0]) and close(b, want[1]) and close(c, want[2])
+    assert a == b and c != a
+
+
+def test_emcee_style_loop_and_batch_agree():
+    """The reference's driver: log_prob(P) = set_param_vector(P); log_likelihood(priors)
+    (examples/single.ipynb:458-460) -- and the batched front-end gives the same numbers."""
+    import scipy.stats as st
+
+    g = load_golden("model_large.npz")
+    o = synth.make_order(N=1024)
+    m = build(o)
+    priors = {"vsini": st.uniform(0, 500), "T": st.norm(6050, 100), "cheb:1": st.uniform(-3, 6)}
+    P = g["n1024_batch_P"][:6]
+
+    def log_prob(p):
+        m.set_param_vector(p)
+        return m.log_likelihood(priors)
+
+    serial = np.array([log_prob(p) for p in P])
+    prior_terms = np.array([sum(pr.logpdf(p[m.labels.index(k)]) for k, pr in priors.items()) for p in P])
+    for b in range(6):
+        assert close(serial[b] - prior_terms[b], g["n1024_batch_lnl"][b])
+    batch = m.log_likelihood_batch(P, priors)
+    np.testing.assert_allclose(batch, serial, rtol=1e-12)
+    # non-finite prior -> -inf without touching the device; out-of-grid walker -> -inf + info
+    bad = P.copy()
+    bad[1, m.labels.index("vsini")] = -5.0
+    bad[2, m.labels.index("T")] = 7000.0
+    ll, info = m.log_likelihood_batch(bad, priors, return_info=True)
+    assert ll[1] == -np.inf and ll[2] == -np.inf and info[2] == -1 and np.isfinite(ll[0])
+
+
+def test_scalar_path_raises_like_the_reference():
+    o = synth.make_order(N=256, m=4, seed=5)
+    m = build(o)
+    m["T"] = 7000.0
+    with pytest.raises(ValueError):
+        m.log_likelihood()
+    m["T"] = 6050.0
+    m["vsini"] = -1.0
+    with pytest.raises(ValueError):
+        m.log_likelihood()
+    with pytest.raises(ValueError):
+        m()
+
+
+def test_emulator_call_api():
+    g = load_golden("emulator.npz")
+    o = synth.make_order(N=256, m=8, seed=3)
+    emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"],
+                   o["w_hat"], o["flux_mean"], o["flux_std"], o["factors"])
+    np.testing.assert_allclose(emu.v11, g["a_v11"], rtol=1e-12, atol=1e-12)
+    with pytest.warns(UserWarning):
+        mu, cov = emu(g["a_queries"][0])
+    emu._trained = True
+    np.testing.assert_allclose(mu, g["a_mu_0"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(cov, g["a_cov_0"], rtol=1e-9, atol=1e-9)
+    mu2, var2 = emu(g["a_queries"][:3], full_cov=False, reinterpret_batch=True)
+    assert mu2.shape == (3, 8) and var2.shape == (3, 8)
+    np.testing.assert_allclose(var2[1], np.diag(g["a_cov_1"]), rtol=1e-9)
+    with pytest.raises(ValueError):
+        emu([5000.0, 4.2, -0.3])
+    with pytest.raises(ValueError):
+        emu(g["a_queries"][:2], full_cov=True, reinterpret_batch=True)
+    np.testing.assert_allclose(emu.bulk_fluxes, g["a_bulk"])
+
+
+def test_echelle_model_sums_orders():
+    orders = [synth.make_order(N=256, m=4, seed=5, wave0=5000.0 * 1.02**k) for k in range(3)]
+    o0 = orders[0]
+    emu_wl = np.concatenate([o["emu_wl"] for o in orders])
+    # one emulator spanning all orders: re-use order 0's recipe on a wide grid
+    wide = synth.make_order(N=256, m=4, seed=5, wave0=5000.0, pad=20.0)
+    from starfish_amd.utils import create_log_lam_grid
+
+    wl = create_log_lam_grid(2.0, emu_wl.min(), emu_wl.max())["wl"]
+    rng = np.random.default_rng(0)
+    q, _ = np.linalg.qr(rng.standard_normal((len(wl), 4)))
+    emu = Emulator(wide["grid_points"], wide["param_names"], wl, wide["weights"], np.ascontiguousarray(q.T),
+                   wide["w_hat"], 1 + 0.1 * np.sin(wl / 7), 0.05 + 0.01 * np.cos(wl / 3), wide["factors"])
+    emu._trained = True
+    waves = np.vstack([o["wave"] for o in orders])
+    fluxes = np.vstack([o["flux"] for o in orders])
+    sig = np.vstack([o["sigma"] for o in orders])
+    data = Spectrum(waves, fluxes, sig)
+    shared = dict(vz=10.0, vsini=30.0, log_scale=0.0, global_cov=dict(log_amp=-9.0, log_ls=np.log(10.0)),
+                  cheb=[0.01, -0.02])
+    em = EchelleModel(emu, data, [6050.0, 4.2, -0.3], **shared)
+    total = em.log_likelihood()
+    parts = [SpectrumModel(emu, Spectrum(waves[k], fluxes[k], sig[k]), [6050.0, 4.2, -0.3],
+                           **{k2: (dict(v) if isinstance(v, dict) else v) for k2, v in shared.items()}).log_likelihood()
+             for k in range(3)]
+    assert close(total, sum(parts))
+    P = np.tile(em.get_param_vector(), (4, 1))
+    P[:, em.labels.index("vz")] += [0.0, 0.1, -0.1, 0.2]
+    batch = em.log_likelihood_batch(P)
+    assert close(batch[0], total) and batch.shape == (4,)

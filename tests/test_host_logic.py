@@ -1,0 +1,194 @@
+"""CPU-only tests: parameter book-keeping of SpectrumModel (mirrors the reference's
+tests/test_models/test_models.py parameter tests), FlatterDict, grids, the TOML round trip, and that
+the product refuses to compute without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from starfish_amd import Spectrum, synth
+from starfish_amd._flatdict import FlatterDict
+from starfish_amd.emulator import Emulator
+from starfish_amd.models import SpectrumModel
+from starfish_amd.utils import calculate_dv, create_log_lam_grid
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def make_model(**over):
+    o = synth.make_order(N=128, m=3, seed=9)
+    emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"],
+                   o["w_hat"], o["flux_mean"], o["flux_std"], o["factors"])
+    emu._trained = True
+    data = Spectrum(o["wave"], o["flux"], sigmas=o["sigma"])
+    c = synth.centre_params(o)
+    c.update(over)
+    gp = c.pop("grid_params")
+    return SpectrumModel(emu, data, grid_params=gp, **c)
+
+
+def test_label_order_matches_reference_convention():
+    m = make_model()
+    assert m.labels == synth.LABELS  # kwargs order, cheb moved last, then emulator param names
+    np.testing.assert_allclose(m.get_param_vector(), synth.centre_vector(dict(wave=m.data.wave)))
+
+
+def test_get_set_param_vector_roundtrip_and_length_check():
+    m = make_model()
+    P0 = m.get_param_vector()
+    m.set_param_vector(P0 + 1)
+    np.testing.assert_allclose(m.get_param_vector(), P0 + 1)
+    with pytest.raises(ValueError):
+        m.set_param_vector(P0[:-1])
+
+
+def test_freeze_thaw_groups():
+    m = make_model()
+    m.freeze("global_cov")
+    assert "global_cov:log_amp" not in m.labels and "global_cov" in m.frozen
+    m.freeze("local_cov")
+    assert not any(k.startswith("local_cov") for k in m.labels)
+    m.freeze("cheb")
+    assert not any(k.startswith("cheb") for k in m.labels)
+    before = m["global_cov:log_amp"]
+    m.set_param_dict({"global_cov": {"log_amp": 100.0}})
+    assert m["global_cov:log_amp"] == before  # frozen values are not overwritten
+    m.thaw(["global_cov", "local_cov", "cheb"])
+    assert m.labels == synth.LABELS
+    m.freeze("all")
+    assert m.labels == ()
+    m.thaw("all")
+    assert m.frozen == []
+    m.freeze("vz")
+    m.set_param_vector(m.get_param_vector())
+    assert "vz" not in m.labels and m["vz"] == 10.0
+
+
+def test_setitem_getitem_delitem():
+    m = make_model()
+    m["vsini"] = 12.0
+    assert m["vsini"] == 12.0
+    m["global_cov:log_amp"] = -3.0
+    assert m.params["global_cov"]["log_amp"] == -3.0
+    m["cheb:4"] = 0.5
+    assert m["cheb"] == [0.01, -0.02, 0, 0.5]
+    with pytest.raises(KeyError):
+        m["cheb:0"] = 1.0
+    with pytest.raises(KeyError):
+        m["garbage"] = 1.0
+    with pytest.raises(KeyError):
+        m["global_cov:garbage"] = 1.0
+    m["cheb"] = [0.3]
+    assert m["cheb"] == [0.3]
+    del m["global_cov"]
+    assert "global_cov" not in m.params and m._glob_cov is None
+    with pytest.raises(KeyError):
+        del m["global_cov"]
+    m["T"] = 6100.0
+    np.testing.assert_allclose(m.grid_params, [6100.0, 4.2, -0.3])
+
+
+def test_multi_order_data_is_rejected():
+    o = synth.make_order(N=64, m=2)
+    emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"],
+                   o["w_hat"], o["flux_mean"], o["flux_std"], o["factors"])
+    data = Spectrum(np.vstack([o["wave"]] * 2), np.vstack([o["flux"]] * 2))
+    with pytest.raises(ValueError):
+        SpectrumModel(emu, data, grid_params=[6050, 4.2, -0.3])
+
+
+def test_toml_roundtrip(tmp_path):
+    m = make_model()
+    m.freeze("vz")
+    path = tmp_path / "model.toml"
+    m.save(path, metadata={"note": "unit test"})
+    m2 = make_model(vz=99.0)
+    m2.load(path)
+    assert m2.params == m.params
+    assert m2.frozen == m.frozen
+    assert m2["local_cov:0:mu"] == m["local_cov:0:mu"]
+
+
+def test_flatterdict_semantics():
+    fd = FlatterDict({"a": 1, "g": {"x": 2, "y": 3}, "l": [{"mu": 1.0}, {"mu": 2.0}]})
+    assert fd.keys() == ["a", "g:x", "g:y", "l:0:mu", "l:1:mu"]
+    assert "g" in fd and "g:x" in fd and "g:z" not in fd
+    assert fd["l:1:mu"] == 2.0
+    fd["g:y"] = 30
+    assert fd["g"]["y"] == 30
+    assert fd.as_dict()["l"] == [{"mu": 1.0}, {"mu": 2.0}]
+    child = fd["g"]
+    child["x"] = -2
+    assert fd["g:x"] == -2
+    del fd["g:x"]
+    assert fd.keys() == ["a", "g:y", "l:0:mu", "l:1:mu"]
+    flat = FlatterDict()
+    flat["p:0:q"] = 5
+    assert flat.as_dict() == {"p": {"0": {"q": 5}}}
+    assert FlatterDict({"a": {"b": 1}}) == FlatterDict({"a": {"b": 1}})
+
+
+def test_spectrum_containers():
+    w = np.linspace(1e4, 4e4, 24).reshape(2, 12)
+    s = Spectrum(w, np.ones_like(w), name="x")
+    assert s.shape == (2, 12) and len(s) == 2 and s.sigmas.shape == (2, 12)
+    r = s.reshape((4, 6))
+    assert r.shape == (4, 6)
+    s.shape = (1, 24)
+    assert s.shape == (1, 24)
+    mask = np.zeros(24, bool)
+    mask[5:15] = True
+    s1 = Spectrum(w.reshape(-1), np.arange(24.0), masks=mask)
+    assert s1[0].wave.shape == (10,) and s1[0].flux[0] == 5.0
+
+
+def test_log_lambda_grid_properties():
+    g = create_log_lam_grid(2.0, 5000.0, 5100.0)
+    wl = g["wl"]
+    assert len(wl) & (len(wl) - 1) == 0
+    assert calculate_dv(wl) <= 2.0
+    assert abs(wl[0] - 5000.0) < 1e-9 and abs(wl[-1] - 5100.0) < 1e-9
+    with pytest.raises(ValueError):
+        create_log_lam_grid(2.0, 5100.0, 5000.0)
+    with pytest.raises(ValueError):
+        create_log_lam_grid(2.0, -1.0, 5000.0)
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from starfish_amd import _lib
+
+    lib = _lib.load()  # loading needs no GPU
+    header = open(os.path.join(ROOT, "include", "starfish_amd.h")).read()
+    declared = set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/starfish_amd.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert lib.sf_version().startswith(b"starfish_amd")
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from starfish_amd import _lib, transforms
+    from starfish_amd.models.kernels import global_covariance_matrix
+
+    with pytest.raises(_lib.StarfishAMDError):
+        global_covariance_matrix(np.linspace(5000, 5001, 8), 1.0, 1.0)
+    with pytest.raises(_lib.StarfishAMDError):
+        transforms.rotational_broaden(np.linspace(5000, 5001, 8), np.ones(8), 10.0)
+    with pytest.raises(_lib.StarfishAMDError):
+        make_model().log_likelihood()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "starfish_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|sf_oracle\s+import|oracle/", text, re.M), \
+                    f"{f} reaches into oracle/"
