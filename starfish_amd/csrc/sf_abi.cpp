@@ -442,7 +442,7 @@ struct Carve {
     }
 };
 struct Work {
-    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *Xraw, *fraw, *resid, *Y, *C, *ztrsv;
+    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf;
     double2* fft;
     int *info_e, *info_c;
     size_t bytes;
@@ -467,6 +467,7 @@ static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, siz
     w.resid = k.take<double>(b * c->npad);
     w.Y = k.take<double>(b * c->mpad * c->npad);
     w.ztrsv = k.take<double>(b * c->npad);
+    w.ltbuf = k.take<double>(b * SF_LTB_DOUBLES);
     w.C = need_C ? k.take<double>(b * (size_t)c->npad * c->lda) : nullptr;
     w.bytes = sf_align_up(k.off, 256);
     return w;
@@ -695,12 +696,12 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
     hipStream_t s = (hipStream_t)stream;
     Work w = carve(c, mdl, B, d_work, work_bytes, true);
     g_prof.calls += 1;
+    const int64_t stride = (int64_t)c->npad * c->lda;
     {
         ProfScope ps(s, PS_TRANSFORM);
         rc = run_transforms(c, mdl, B, d_params, w, nullptr, nullptr, d_resid, d_log_scale, true, s);
         if (rc) return rc;
     }
-    const int64_t stride = (int64_t)c->npad * c->lda;
     {
         ProfScope ps(s, PS_FILL);
         sf_fill_args f = fill_args(c, mdl, d_params, w);
@@ -714,13 +715,13 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
     }
     {
         ProfScope ps(s, PS_POTRF);
-        rc = sf_launch_potrf(w.C, c->npad, c->lda, stride, B, w.info_c, s);
+        // the residual rides through the factorisation: w.resid is overwritten with z = L^-1 R
+        rc = sf_launch_potrf(w.C, c->npad, c->lda, stride, B, w.info_c, w.ltbuf, w.resid, c->npad, s);
         if (rc) return rc;
     }
     {
         ProfScope ps(s, PS_SOLVE);
-        rc = sf_launch_logdet_sqmah(w.C, c->npad, c->lda, stride, B, w.resid, c->npad, w.ztrsv, w.logdet,
-                                    w.sqmah, s);
+        rc = sf_launch_logdet_z(w.C, c->npad, c->lda, stride, B, w.resid, c->npad, w.logdet, w.sqmah, s);
         if (rc) return rc;
         rc = sf_launch_finish(B, w.logdet, w.sqmah, w.info_e, w.info_c, d_lnl, d_info, s);
         if (rc) return rc;
@@ -865,18 +866,19 @@ extern "C" int sf_chebyshev_correct(const double* d_wave, int n, double wave_max
 
 extern "C" size_t sf_potrf_workspace_bytes(int n, int batch) {
     if (n <= 0 || batch <= 0) return 0;
-    return sf_align_up(sizeof(double) * (size_t)n * batch, 256) + 256;
+    // z scratch of the stand-alone solve + the transposed leaf factor read by the panel solves
+    return sf_align_up(sizeof(double) * (size_t)n * batch, 256) +
+           sf_align_up(sizeof(double) * (size_t)SF_LTB_DOUBLES * batch, 256) + 256;
 }
 extern "C" int sf_potrf_batch(double* d_A, int n, int lda, int64_t stride, int batch, int* d_info, void* d_work,
                               size_t work_bytes, void* stream) {
-    (void)d_work;
-    (void)work_bytes;
-    if (!d_A || !d_info) {
-        sf_set_error("sf_potrf_batch: bad argument");
+    if (!d_A || !d_info || !d_work || work_bytes < sf_potrf_workspace_bytes(n, batch)) {
+        sf_set_error("sf_potrf_batch: bad argument or workspace");
         return SF_EINVAL;
     }
+    double* ltbuf = (double*)((char*)d_work + sf_align_up(sizeof(double) * (size_t)n * batch, 256));
     ProfScope ps((hipStream_t)stream, PS_POTRF);
-    return sf_launch_potrf(d_A, n, lda, stride, batch, d_info, (hipStream_t)stream);
+    return sf_launch_potrf(d_A, n, lda, stride, batch, d_info, ltbuf, nullptr, 0, (hipStream_t)stream);
 }
 extern "C" int sf_logdet_sqmah_batch(const double* d_L, int n, int lda, int64_t stride, int batch,
                                      const double* d_R, int ldr, void* d_work, size_t work_bytes,

@@ -133,81 +133,117 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(double* __restrict__ base, i
         }
 }
 
-// 64 x 64 diagonal block at (c, c): unblocked right-looking Cholesky in LDS (dpotf2 order:
-// pivot sqrt, column scale by the reciprocal pivot, rank-1 update of the trailing triangle).
-__global__ __launch_bounds__(256) void k_potrf_leaf(double* __restrict__ base, int lda, int64_t stride,
-                                                    int c, int* __restrict__ info) {
-    __shared__ double T[SF_LEAF * (SF_LEAF + 1)];
-    const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ double sf_readlane_d(double v, int srclane) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], srclane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], srclane);
+    return u.d;
+}
+
+// 64 x 64 diagonal block at (c, c), ONE wave per matrix: lane r keeps row r in registers and the
+// unblocked right-looking Cholesky (dpotf2 order: pivot sqrt, column scale by the reciprocal pivot,
+// rank-1 update) broadcasts column entries with v_readlane -- no LDS, no barriers.
+// Besides L (written in place) it leaves Lt[k][j] = L[j][k] (j > k), Lt[k][k] = 1 / L[k][k] in the
+// read-only side buffer `ltbuf` that k_trsm_leaf fetches through the scalar cache.
+// With a right-hand side (rhs != NULL) the forward substitution L z = R rides along: lane r carries
+// R[c + r]; after column k is final, z_k = R_k / L_kk is broadcast and R_r -= L_rk z_k (r > k).
+#define SF_LTB (SF_LEAF * SF_LEAF + SF_LEAF)  // doubles per matrix in the side buffer: Lt + z
+__global__ __launch_bounds__(64) void k_potrf_leaf(double* __restrict__ base, int lda, int64_t stride,
+                                                   int c, int* __restrict__ info,
+                                                   double* __restrict__ ltbuf, double* __restrict__ rhs,
+                                                   int ldr) {
+    const int b = blockIdx.x, r = threadIdx.x;
     double* D = base + (int64_t)b * stride + (int64_t)c * lda + c;
-    for (int e = tid; e < SF_LEAF * SF_LEAF; e += 256) {
-        const int i = e >> 6, j = e & 63;
-        T[i * 65 + j] = D[(int64_t)i * lda + j];
+    double* prow = D + (int64_t)r * lda;
+    double a[SF_LEAF];
+#pragma unroll
+    for (int j = 0; j < SF_LEAF; j += 2) {
+        const double2 v = *(const double2*)(prow + j);
+        a[j] = v.x;
+        a[j + 1] = v.y;
     }
-    const int ty = tid >> 4, tx = tid & 15;
     int bad = 0;
+    double* lt = ltbuf + (int64_t)b * SF_LTB;
+    double rv = rhs ? rhs[(int64_t)b * ldr + c + r] : 0.0;
+#pragma unroll
     for (int k = 0; k < SF_LEAF; ++k) {
-        __syncthreads();
-        const double akk = T[k * 65 + k];
+        const double akk = sf_readlane_d(a[k], k);
         if (!(akk > 0.0) && !bad) bad = c + k + 1;
         const double d = sqrt(akk);
         const double inv = 1.0 / d;
-        for (int i = k + 1 + ty; i < SF_LEAF; i += 16) {
-            const double lik = T[i * 65 + k] * inv;
-            for (int j = k + 1 + tx; j <= i; j += 16) T[i * 65 + j] -= lik * (T[j * 65 + k] * inv);
-        }
-        __syncthreads();
-        if (tid < SF_LEAF) {
-            if (tid > k)
-                T[tid * 65 + k] *= inv;
-            else if (tid == k)
-                T[k * 65 + k] = d;
+        a[k] = (r > k) ? a[k] * inv : ((r == k) ? d : 0.0);
+        lt[k * SF_LEAF + r] = (r == k) ? inv : a[k];
+        const double zk = sf_readlane_d(rv, k) * inv;
+        rv = (r > k) ? rv - a[k] * zk : ((r == k) ? zk : rv);
+#pragma unroll
+        for (int j = k + 1; j < SF_LEAF; ++j) {
+            const double ljk = sf_readlane_d(a[k], j);
+            a[j] -= a[k] * ljk;
         }
     }
-    __syncthreads();
-    for (int e = tid; e < SF_LEAF * SF_LEAF; e += 256) {
-        const int i = e >> 6, j = e & 63;
-        if (j <= i) D[(int64_t)i * lda + j] = T[i * 65 + j];
+    // lower triangle back in place (entries above the diagonal of row r are left untouched)
+#pragma unroll
+    for (int j = 0; j < SF_LEAF; ++j)
+        if (j <= r) prow[j] = a[j];
+    if (rhs) {
+        rhs[(int64_t)b * ldr + c + r] = rv;  // z of this block
+        lt[SF_LEAF * SF_LEAF + r] = rv;
     }
-    if (tid == 0 && bad && info[b] == 0) info[b] = bad;
+    if (r == 0 && bad && info[b] == 0) info[b] = bad;
 }
 
-// Rows below a factored 64 x 64 block:  X L^T = A  solved in place, one matrix row per lane
-// (x[64] lives in registers; column k of L is read from LDS as a broadcast of row k of L^T).
-__global__ __launch_bounds__(256) void k_trsm_leaf(double* __restrict__ base, int lda, int64_t stride,
-                                                   int c, int n) {
-    __shared__ __attribute__((aligned(16))) double Lt[SF_LEAF * SF_LEAF];  // Lt[k][j] = L[j][k]
-    __shared__ double rd[SF_LEAF];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    double* Mx = base + (int64_t)b * stride;
-    const double* D = Mx + (int64_t)c * lda + c;
-    for (int e = tid; e < SF_LEAF * SF_LEAF; e += 256) {
-        const int j = e >> 6, k = e & 63;  // coalesced read of L[j][k]
-        Lt[k * SF_LEAF + j] = D[(int64_t)j * lda + k];
+// Rows below a factored 64 x 64 block:  X L^T = A  solved in place.  One wave handles 64 rows: the
+// 64 x 64 slab is fetched with coalesced 16-byte loads (two full rows per instruction), transposed
+// through LDS so that lane r owns row r in registers, eliminated with one v_fma_f64 per element whose
+// L^T operand comes from the read-only side buffer through the scalar cache, and written back the
+// same way.  With a right-hand side, the row's entry is updated right-looking: R[row] -= x . z_block.
+__global__ __launch_bounds__(64) void k_trsm_leaf(double* __restrict__ base, int lda, int64_t stride,
+                                                  int c, int n, const double* __restrict__ ltbuf,
+                                                  double* __restrict__ rhs, int ldr) {
+    __shared__ double tile[SF_LEAF * (SF_LEAF + 1)];
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const double* __restrict__ Lt = ltbuf + (int64_t)b * SF_LTB;
+    const int row0 = c + SF_LEAF + blockIdx.x * SF_LEAF;
+    const int nvalid = min(SF_LEAF, n - row0);
+    double* slab = base + (int64_t)b * stride + (int64_t)row0 * lda + c;
+    const int half = lane >> 5, col2 = (lane & 31) * 2;
+#pragma unroll 8
+    for (int i = 0; i < SF_LEAF / 2; ++i) {
+        const int rr = 2 * i + half;
+        if (rr < nvalid) {
+            const double2 v = *(const double2*)(slab + (int64_t)rr * lda + col2);
+            tile[rr * 65 + col2] = v.x;
+            tile[rr * 65 + col2 + 1] = v.y;
+        }
     }
     __syncthreads();
-    if (tid < SF_LEAF) rd[tid] = 1.0 / Lt[tid * SF_LEAF + tid];
-    __syncthreads();
-
-    const int row = c + SF_LEAF + blockIdx.x * 256 + tid;
-    if (row >= n) return;
-    double* p = Mx + (int64_t)row * lda + c;
     double x[SF_LEAF];
 #pragma unroll
-    for (int j = 0; j < SF_LEAF; j += 2) {
-        const double2 v = *(const double2*)(p + j);
-        x[j] = v.x;
-        x[j + 1] = v.y;
-    }
+    for (int j = 0; j < SF_LEAF; ++j) x[j] = tile[lane * 65 + j];
 #pragma unroll
     for (int k = 0; k < SF_LEAF; ++k) {
-        x[k] *= rd[k];
+        x[k] *= Lt[k * SF_LEAF + k];
         const double xk = x[k];
 #pragma unroll
         for (int j = k + 1; j < SF_LEAF; ++j) x[j] -= xk * Lt[k * SF_LEAF + j];
     }
 #pragma unroll
-    for (int j = 0; j < SF_LEAF; j += 2) *(double2*)(p + j) = make_double2(x[j], x[j + 1]);
+    for (int j = 0; j < SF_LEAF; ++j) tile[lane * 65 + j] = x[j];
+    if (rhs && lane < nvalid) {
+        const double* __restrict__ z = Lt + SF_LEAF * SF_LEAF;
+        double acc = rhs[(int64_t)b * ldr + row0 + lane];
+#pragma unroll
+        for (int j = 0; j < SF_LEAF; ++j) acc -= x[j] * z[j];
+        rhs[(int64_t)b * ldr + row0 + lane] = acc;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int i = 0; i < SF_LEAF / 2; ++i) {
+        const int rr = 2 * i + half;
+        if (rr < nvalid)
+            *(double2*)(slab + (int64_t)rr * lda + col2) = make_double2(tile[rr * 65 + col2], tile[rr * 65 + col2 + 1]);
+    }
 }
 
 __device__ __forceinline__ double sf_wave_sum(double v) {
@@ -310,25 +346,65 @@ static int launch_gemm(double* A, int lda, int64_t stride, int batch, int r0, in
     return SF_OK;
 }
 
-int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, hipStream_t s) {
-    if (n % SF_LEAF != 0 || lda < n || batch <= 0) {
-        sf_set_error("potrf: n must be a positive multiple of %d, lda >= n", SF_LEAF);
+// One workgroup per matrix: logdet = 2 sum log L_ii and sqmah = |z|^2 where z = L^-1 R was produced
+// in place of R by the factorisation (k_potrf_leaf / k_trsm_leaf with a right-hand side).
+__global__ __launch_bounds__(256) void k_logdet_z(const double* __restrict__ base, int n, int lda,
+                                                  int64_t stride, const double* __restrict__ zbuf, int ldr,
+                                                  double* __restrict__ logdet,
+                                                  double* __restrict__ sqmah) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const double* Mx = base + (int64_t)b * stride;
+    const double* z = zbuf + (int64_t)b * ldr;
+    double slog = 0.0, ssq = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        slog += log(Mx[(int64_t)i * lda + i]);
+        const double zi = z[i];
+        ssq += zi * zi;
+    }
+    slog = sf_wave_sum(slog);
+    ssq = sf_wave_sum(ssq);
+    if (lane == 0) {
+        red[w] = slog;
+        red[4 + w] = ssq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        logdet[b] = 2.0 * (red[0] + red[1] + red[2] + red[3]);
+        sqmah[b] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batch, const double* z, int ldr,
+                       double* logdet, double* sqmah, hipStream_t s) {
+    hipLaunchKernelGGL(k_logdet_z, dim3(batch), dim3(256), 0, s, L, n, lda, stride, z, ldr, logdet, sqmah);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+// Factor each n x n matrix in place; with rhs != NULL (batch x ldr) the forward substitution
+// L z = rhs is fused into the leaf kernels and z overwrites rhs.
+int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* ltbuf,
+                    double* rhs, int ldr, hipStream_t s) {
+    const int nrows = n;
+    if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !ltbuf) {
+        sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
         return SF_EINVAL;
     }
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
     for (int k0 = 0; k0 < n; k0 += SF_NB) {
         const int k1 = (k0 + SF_NB < n) ? k0 + SF_NB : n;
         if (k0 > 0) {
-            int rc = launch_gemm(A, lda, stride, batch, k0, k0, 0, n - k0, k1 - k0, k0, 1, s);
+            int rc = launch_gemm(A, lda, stride, batch, k0, k0, 0, nrows - k0, k1 - k0, k0, 1, s);
             if (rc) return rc;
         }
         for (int c = k0; c < k1; c += SF_LEAF) {
-            hipLaunchKernelGGL(k_potrf_leaf, dim3(batch), dim3(256), 0, s, A, lda, stride, c, info);
+            hipLaunchKernelGGL(k_potrf_leaf, dim3(batch), dim3(64), 0, s, A, lda, stride, c, info, ltbuf, rhs, ldr);
             SF_LAUNCH_CHECK();
-            const int below = n - (c + SF_LEAF);
+            const int below = nrows - (c + SF_LEAF);
             if (below > 0) {
-                hipLaunchKernelGGL(k_trsm_leaf, dim3((below + 255) / 256, batch), dim3(256), 0, s, A,
-                                   lda, stride, c, n);
+                hipLaunchKernelGGL(k_trsm_leaf, dim3((below + 63) / 64, batch), dim3(64), 0, s, A,
+                                   lda, stride, c, nrows, (const double*)ltbuf, rhs, ldr);
                 SF_LAUNCH_CHECK();
             }
             if (c + SF_LEAF < k1) {

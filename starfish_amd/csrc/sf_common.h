@@ -39,7 +39,11 @@ void sf_prof_gemm_end(void* tok);
 
 // ---- launchers implemented in the .hip files (all enqueue on `s`, never synchronise) ----------
 // sf_chol.hip
-int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, hipStream_t s);
+#define SF_LTB_DOUBLES (SF_LEAF * SF_LEAF + SF_LEAF)  // side buffer per matrix: L^T of the leaf + its z
+int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* ltbuf,
+                    double* rhs, int ldr, hipStream_t s);
+int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batch, const double* z, int ldr,
+                       double* logdet, double* sqmah, hipStream_t s);
 int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int batch,
                            const double* R, int ldr, double* zscratch, double* logdet, double* sqmah, hipStream_t s);
 
