@@ -467,7 +467,7 @@ static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, siz
     w.resid = k.take<double>(b * c->npad);
     w.Y = k.take<double>(b * c->mpad * c->npad);
     w.ztrsv = k.take<double>(b * c->npad);
-    w.ltbuf = k.take<double>(b * SF_LTB_DOUBLES);
+    w.ltbuf = need_C ? k.take<double>(sf_potrf_work_doubles(c->npad, B)) : nullptr;  // Cholesky scratch
     w.C = need_C ? k.take<double>(b * (size_t)c->npad * c->lda) : nullptr;
     w.bytes = sf_align_up(k.off, 256);
     return w;
@@ -868,7 +868,7 @@ extern "C" size_t sf_potrf_workspace_bytes(int n, int batch) {
     if (n <= 0 || batch <= 0) return 0;
     // z scratch of the stand-alone solve + the transposed leaf factor read by the panel solves
     return sf_align_up(sizeof(double) * (size_t)n * batch, 256) +
-           sf_align_up(sizeof(double) * (size_t)SF_LTB_DOUBLES * batch, 256) + 256;
+           sf_align_up(sizeof(double) * sf_potrf_work_doubles(n, batch), 256) + 256;
 }
 extern "C" int sf_potrf_batch(double* d_A, int n, int lda, int64_t stride, int batch, int* d_info, void* d_work,
                               size_t work_bytes, void* stream) {

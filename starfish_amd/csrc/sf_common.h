@@ -40,7 +40,9 @@ void sf_prof_gemm_end(void* tok);
 // ---- launchers implemented in the .hip files (all enqueue on `s`, never synchronise) ----------
 // sf_chol.hip
 #define SF_LTB_DOUBLES (SF_LEAF * SF_LEAF + SF_LEAF)  // side buffer per matrix: L^T of the leaf + its z
-int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* ltbuf,
+#define SF_LDT (SF_NB + 16)                            // row stride of the panel scratch
+size_t sf_potrf_work_doubles(int n, int batch);        // doubles of scratch sf_launch_potrf needs
+int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
                     double* rhs, int ldr, hipStream_t s);
 int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batch, const double* z, int ldr,
                        double* logdet, double* sqmah, hipStream_t s);
