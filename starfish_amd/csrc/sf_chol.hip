@@ -9,6 +9,9 @@
 //   inside a panel, 64-column steps:  k_potrf_leaf (64x64 in LDS)  ->  k_trsm_leaf (row-per-lane
 //     substitution, x in registers, L^T broadcast from LDS)  ->  k_gemm_nt with K = 64.
 //   k_trsv_logdet: one forward substitution L z = R per matrix (sqmah = z.z) and 2 sum log L_ii.
+#include <cstdlib>
+#include <vector>
+
 #include "sf_common.h"
 
 #define GT 128  // C tile edge of the MFMA kernel
@@ -50,6 +53,10 @@ struct sf_gemm_args {
     double* rhs;
     const double* z;
     int64_t srhs, sz;
+    // block-diagonal mode (diag_blocks > 0): the launch updates diag_blocks independent SF_NB x SF_NB
+    // diagonal blocks; block j takes A/B at +j*dA and C at +j*dC (M = Nc = total rows covered)
+    int diag_blocks;
+    int64_t dA, dC;
     int mt, nt;
 };
 
@@ -67,12 +74,30 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
     const int tiles = g.mt * g.nt;
     const int b = id / tiles;
     const int t = id - b * tiles;
-    const int tm = t / g.nt, tn = t - tm * g.nt;
+    int tm, tn, rows_here, cols_here;
+    if (g.diag_blocks) {
+        // 2 x 2 tiles per SF_NB block, the upper-right one is never needed
+        const int jb = t >> 2;
+        tm = (t >> 1) & 1;
+        tn = t & 1;
+        if (tn > tm) return;
+        const int blk = min(SF_NB, g.M - jb * SF_NB);  // the last block may be narrower
+        rows_here = min(GT, blk - tm * GT);
+        cols_here = min(GT, blk - tn * GT);
+        if (rows_here <= 0 || cols_here <= 0) return;
+        g.A += jb * g.dA;
+        g.B += jb * g.dA;
+        if (g.Cin) g.Cin += jb * g.dC;
+        g.Cout += jb * g.dC;
+        if (RHS && g.rhs) g.rhs += jb * SF_NB;
+    } else {
+        tm = t / g.nt;
+        tn = t - tm * g.nt;
+        if (g.tri && tn * GT > tm * GT + GT - 1) return;
+        rows_here = min(GT, g.M - tm * GT);
+        cols_here = min(GT, g.Nc - tn * GT);
+    }
     const int row0 = tm * GT, col0 = tn * GT;
-    if (g.tri && col0 > row0 + GT - 1) return;
-
-    const int rows_here = min(GT, g.M - row0);
-    const int cols_here = min(GT, g.Nc - col0);
     const int Kt = g.btri ? min(g.K, col0 + GT) : g.K;
 
     const int tid = threadIdx.x;
@@ -97,10 +122,18 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
             }
         }
 
-    // ---- global -> register -> LDS staging: thread covers rows lr+64p, two doubles at column lc
+    // ---- global -> register -> LDS staging: thread covers rows lr+64p, two doubles at column lc.
+    // Rows past the block edge are CLAMPED to the last valid row instead of being predicated: the
+    // duplicated data only feeds accumulator rows / columns that are never stored, and the loads stay
+    // branch-free (a predicated load makes hipcc wait for the whole vm queue).
     const int lr = tid >> 3, lc = (tid & 7) * 2;
-    const double* Ag = g.A + (int64_t)b * g.sA + (int64_t)(row0 + lr) * g.lda + lc;
-    const double* Bg = g.B + (int64_t)b * g.sB + (int64_t)(col0 + lr) * g.ldb + lc;
+    const double* Ap[2];
+    const double* Bp[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        Ap[p] = g.A + (int64_t)b * g.sA + (int64_t)(row0 + min(lr + 64 * p, rows_here - 1)) * g.lda + lc;
+        Bp[p] = g.B + (int64_t)b * g.sB + (int64_t)(col0 + min(lr + 64 * p, cols_here - 1)) * g.ldb + lc;
+    }
     double2 ra[2], rb[2];
     const bool do_rhs = RHS && g.rhs && (tm == tn);
     const double* zg = do_rhs ? g.z + (int64_t)b * g.sz + lc : nullptr;
@@ -110,11 +143,8 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
     auto gload = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int rr = lr + 64 * p;
-            ra[p] = (rr < rows_here) ? *(const double2*)(Ag + (int64_t)(64 * p) * g.lda + kt * GK)
-                                     : make_double2(0.0, 0.0);
-            rb[p] = (rr < cols_here) ? *(const double2*)(Bg + (int64_t)(64 * p) * g.ldb + kt * GK)
-                                     : make_double2(0.0, 0.0);
+            ra[p] = *(const double2*)(Ap[p] + kt * GK);
+            rb[p] = *(const double2*)(Bp[p] + kt * GK);
         }
         if (RHS && do_rhs) zv = *(const double2*)(zg + kt * GK);
     };
@@ -141,9 +171,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
     }
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+    auto compute = [&](int cur) {
         const double* Ab = &As[cur][(wm * 32 + l15) * GLD + lq];
         const double* Bb = &Bs[cur][(wn * 64 + l15) * GLD + lq];
 #pragma unroll
@@ -159,9 +187,16 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
                 for (int ni = 0; ni < 4; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+    };
+    // steady state is ONE basic block: issue the next slab's global loads, run this slab's MFMAs from
+    // LDS, then park the loaded slab in the other LDS buffer; the last slab is peeled
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        gload(kt + 1);
+        compute(kt & 1);
+        lstore((kt & 1) ^ 1);
         __syncthreads();
     }
+    if (nk > 0) compute((nk - 1) & 1);
 
     double* Cout = g.Cout + (int64_t)b * g.sCout + col0;
 #pragma unroll
@@ -392,6 +427,10 @@ static int launch_gemm(sf_gemm_args g, int batch, bool neg, double flops, hipStr
     if (g.M <= 0 || g.Nc <= 0) return SF_OK;
     g.mt = (g.M + GT - 1) / GT;
     g.nt = (g.Nc + GT - 1) / GT;
+    if (g.diag_blocks) {  // 4 tile slots per block
+        g.mt = g.diag_blocks;
+        g.nt = 4;
+    }
     const long long nblk = (long long)g.mt * g.nt * batch;
     if (nblk > 0x7fffffffLL) {
         sf_set_error("gemm grid too large");
@@ -483,18 +522,219 @@ __global__ __launch_bounds__(256) void k_panel_finish(const double* __restrict__
     }
 }
 
-size_t sf_potrf_work_doubles(int n, int batch) {
-    const size_t b = (size_t)batch;
-    return b * SF_LTB_DOUBLES + b * (size_t)(n + SF_NB) * SF_LDT + b * (size_t)SF_NB * SF_LDT + 64;
+// Whole diagonal-block step of one panel in ONE launch (one workgroup per matrix), so that it can run
+// on the side stream next to the big MFMA launches without waiting for CU slots a dozen times:
+//   identity block; for each 64-column leaf: register Cholesky by wave 0 (as k_potrf_leaf, with the
+//   fused forward substitution), row-per-lane solves of all rows below (L^T broadcast from LDS), K = 64
+//   MFMA update of the remaining columns; finally L_kk -> matrix and W^T for the panel solve.
+// S = panel scratch rows [0, 2 pw): diagonal block on top, identity (-> W = L_kk^-T) below.
+__global__ __launch_bounds__(256) void k_panel_diag(double* __restrict__ T, int64_t sT, int pw,
+                                                    int* __restrict__ info, int info_off,
+                                                    double* __restrict__ rhs, int ldr,
+                                                    double* __restrict__ Cdiag, int ldc, int64_t sC,
+                                                    double* __restrict__ Wt, int64_t sW) {
+    __shared__ __attribute__((aligned(16))) double Lt[SF_LEAF * SF_LEAF];
+    __shared__ double zs[SF_LEAF];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double* S = T + (int64_t)b * sT;
+    double* rb = rhs ? rhs + (int64_t)b * ldr : nullptr;
+
+    for (int e = tid; e < pw * pw; e += 256) {
+        const int i = e / pw, j = e - i * pw;
+        S[(int64_t)(pw + i) * SF_LDT + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    for (int c = 0; c < pw; c += SF_LEAF) {
+        // ---- leaf factorisation: lane r of wave 0 owns row c + r
+        if (w == 0) {
+            double* prow = S + (int64_t)(c + lane) * SF_LDT + c;
+            double a[SF_LEAF];
+#pragma unroll
+            for (int j = 0; j < SF_LEAF; j += 2) {
+                const double2 v = *(const double2*)(prow + j);
+                a[j] = v.x;
+                a[j + 1] = v.y;
+            }
+            int bad = 0;
+            double rv = rb ? rb[c + lane] : 0.0;
+#pragma unroll
+            for (int k = 0; k < SF_LEAF; ++k) {
+                const double akk = sf_readlane_d(a[k], k);
+                if (!(akk > 0.0) && !bad) bad = info_off + c + k + 1;
+                const double d = sqrt(akk);
+                const double inv = 1.0 / d;
+                a[k] = (lane > k) ? a[k] * inv : ((lane == k) ? d : 0.0);
+                Lt[k * SF_LEAF + lane] = (lane == k) ? inv : a[k];
+                const double zk = sf_readlane_d(rv, k) * inv;
+                rv = (lane > k) ? rv - a[k] * zk : ((lane == k) ? zk : rv);
+#pragma unroll
+                for (int j = k + 1; j < SF_LEAF; ++j) {
+                    const double ljk = sf_readlane_d(a[k], j);
+                    a[j] -= a[k] * ljk;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SF_LEAF; ++j)
+                if (j <= lane) prow[j] = a[j];
+            zs[lane] = rv;
+            if (rb) rb[c + lane] = rv;
+            if (lane == 0 && bad && info[b] == 0) info[b] = bad;
+        }
+        __syncthreads();
+
+        // ---- rows below: X L^T = A, one row per lane, 64-row chunks dealt to the 4 waves
+        const int o = c + SF_LEAF;
+        const int nrows = 2 * pw - o;
+        for (int q = w; q * SF_LEAF < nrows; q += 4) {
+            const int row = o + q * SF_LEAF + lane;
+            const bool valid = row < 2 * pw;
+            double* p = S + (int64_t)(valid ? row : 2 * pw - 1) * SF_LDT + c;
+            double x[SF_LEAF];
+#pragma unroll
+            for (int j = 0; j < SF_LEAF; j += 2) {
+                const double2 v = *(const double2*)(p + j);
+                x[j] = v.x;
+                x[j + 1] = v.y;
+            }
+#pragma unroll
+            for (int k = 0; k < SF_LEAF; ++k) {
+                x[k] *= Lt[k * SF_LEAF + k];
+                const double xk = x[k];
+#pragma unroll
+                for (int j = k + 1; j < SF_LEAF; ++j) x[j] -= xk * Lt[k * SF_LEAF + j];
+            }
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < SF_LEAF; j += 2) *(double2*)(p + j) = make_double2(x[j], x[j + 1]);
+                if (rb && row < pw) {
+                    double acc = rb[row];
+#pragma unroll
+                    for (int j = 0; j < SF_LEAF; ++j) acc -= x[j] * zs[j];
+                    rb[row] = acc;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- K = 64 update of the remaining columns: S[o:, o:pw] -= S[o:, c:o] S[o:pw, c:o]^T
+        const int Nc = pw - o;
+        if (Nc > 0) {
+            const int ntn = Nc / SF_LEAF, ntm = nrows / 32;
+            const int l15 = lane & 15, lq = lane >> 4;
+            for (int t = w; t < ntm * ntn; t += 4) {
+                const int tm = t / ntn, tn = t - tm * ntn;
+                const int r0 = o + tm * 32, c0 = o + tn * SF_LEAF;
+                if (c0 > r0 + 31) continue;  // entirely above the diagonal of the diagonal block
+                sf_d4 acc[2][4];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[mi][ni][r] = S[(int64_t)(r0 + mi * 16 + lq + 4 * r) * SF_LDT + c0 + ni * 16 + l15];
+                const double* Ab = S + (int64_t)(r0 + l15) * SF_LDT + c + lq;
+                const double* Bb = S + (int64_t)(c0 + l15) * SF_LDT + c + lq;
+#pragma unroll 4
+                for (int ks = 0; ks < SF_LEAF / 4; ++ks) {
+                    double av[2], bv[4];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) av[i] = -Ab[(int64_t)i * 16 * SF_LDT + ks * 4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bv[i] = Bb[(int64_t)i * 16 * SF_LDT + ks * 4];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            S[(int64_t)(r0 + mi * 16 + lq + 4 * r) * SF_LDT + c0 + ni * 16 + l15] = acc[mi][ni][r];
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- L_kk back into the matrix; W^T (lower triangular, zero above) for the panel solve
+    double* Cb = Cdiag + (int64_t)b * sC;
+    double* Wb = Wt + (int64_t)b * sW;
+    for (int e = tid; e < pw * pw; e += 256) {
+        const int i = e / pw, j = e - i * pw;
+        if (j <= i) Cb[(int64_t)i * ldc + j] = S[(int64_t)i * SF_LDT + j];
+    }
+    for (int e = tid; e < pw * pw; e += 256) {
+        const int j = e / pw, cc = e - j * pw;  // read W[j][cc] along a row, scatter to Wt[cc][j]
+        Wb[(int64_t)cc * SF_LDT + j] = (j <= cc) ? S[(int64_t)(pw + j) * SF_LDT + cc] : 0.0;
+    }
 }
 
-// Factor each n x n matrix in place (lower).  Left-looking over panels of SF_NB columns:
-//   U  T <- C[k0:, k0:k1] - L[k0:, :k0] L[k0:k1, :k0]^T        one MFMA launch, C read once, long K
-//   D  factor T's diagonal block together with an identity block -> L_kk and W = L_kk^-T
-//      (64-column leaf steps on the small (2 pw) x pw problem)
-//   G  C[k1:, k0:k1] <- T[below] W                               one MFMA launch (triangular B)
-// With rhs != NULL (batch x ldr) the forward substitution L z = rhs is fused: U applies the
-// left-looking update of rhs[k0:k1] while B streams through LDS, D finishes it; z overwrites rhs.
+size_t sf_potrf_work_doubles(int n, int batch) {
+    const size_t b = (size_t)batch;
+    return b * SF_LTB_DOUBLES + b * (size_t)(n + SF_NB) * SF_LDT + 2 * b * (size_t)SF_NB * SF_LDT + 64;
+}
+
+// ---- two-stream lookahead ---------------------------------------------------------------------
+// The diagonal-block chain (D) is a sequence of small latency-bound launches; it runs on a library
+// owned side stream concurrently with the big MFMA launches of the main stream.
+struct SideStream {
+    int device = -1;
+    hipStream_t s = nullptr;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+};
+static SideStream g_side;
+
+static int side_stream(hipStream_t* out) {
+    int dev = 0;
+    SF_HIP(hipGetDevice(&dev));
+    if (g_side.s == nullptr || g_side.device != dev) {
+        // highest priority: its small launches must win freed CU slots against the thousands of
+        // pending MFMA workgroups of the main stream, otherwise the chain starves
+        int prio_lo = 0, prio_hi = 0;
+        SF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        SF_HIP(hipStreamCreateWithPriority(&g_side.s, hipStreamNonBlocking, prio_hi));
+        g_side.device = dev;
+        g_side.pool.clear();
+    }
+    g_side.used = 0;
+    *out = g_side.s;
+    return SF_OK;
+}
+static int next_event(hipEvent_t* e) {
+    if (g_side.used == g_side.pool.size()) {
+        hipEvent_t ne;
+        SF_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+        g_side.pool.push_back(ne);
+    }
+    *e = g_side.pool[g_side.used++];
+    return SF_OK;
+}
+#define SF_TRY(x)          \
+    do {                   \
+        int rc__ = (x);    \
+        if (rc__) return rc__; \
+    } while (0)
+
+// Factor each n x n matrix in place (lower), panels of SF_NB columns:
+//   Ur  T[below] <- C[k1:, k0:k1] - L[k1:, :k0] L[k0:k1, :k0]^T   LEFT-looking for everything below the
+//                                                                diagonal block: C read once, long K
+//   R   C[jj] -= L[j-rows, k0:k1] L[j-rows, k0:k1]^T for the future DIAGONAL blocks j > k (RIGHT-looking,
+//       K = SF_NB): keeps the next diagonal block ready without a long-K launch of only a few tiles;
+//       its diagonal tiles also apply rhs[j-rows] -= L[j-rows, k0:k1] z[k0:k1]
+//   D   factor the diagonal block together with an identity block -> L_kk and W = L_kk^-T
+//       (64-column leaf steps on the small (2 pw) x pw problem), L_kk -> matrix, W^T (F)
+//   G   C[k1:, k0:k1] <- T[below] W                               MFMA (triangular B)
+// With rhs != NULL (batch x ldr) the forward substitution L z = rhs is fused (R and D); z overwrites rhs.
+//
+// Lookahead (two streams): only the rows of the NEXT diagonal block are on the critical chain.
+//   side:  D(k) F(k) | wait Ur(k) | Gt(k) Rnext(k -> k+1) | D(k+1) ...
+//   main:  wait Gt(k-1) | Ur(k) | wait F(k) | Gr(k) Rrest(k) | ...
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
                     double* rhs, int ldr, hipStream_t s) {
     if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
@@ -504,92 +744,162 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     double* ltbuf = work;
     double* T = ltbuf + (size_t)batch * SF_LTB_DOUBLES;
     const int64_t sT = (int64_t)(n + SF_NB) * SF_LDT;
-    double* Wt = T + (size_t)batch * sT;
+    double* Wt2 = T + (size_t)batch * sT;  // two W^T buffers, alternating by panel parity
     const int64_t sW = (int64_t)SF_NB * SF_LDT;
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
-    for (int k0 = 0; k0 < n; k0 += SF_NB) {
+
+    hipStream_t c = nullptr;  // side ("critical chain") stream
+    SF_TRY(side_stream(&c));
+    static const bool no_lookahead = getenv("SF_NO_LOOKAHEAD") != nullptr;  // tuning aid: single stream
+    static const bool fused_diag = getenv("SF_FUSED_DIAG") != nullptr;      // tuning aid: one-launch D
+    if (no_lookahead) c = s;
+    hipEvent_t e_fork, e_gt_prev = nullptr;
+    SF_TRY(next_event(&e_fork));
+    SF_HIP(hipEventRecord(e_fork, s));
+    SF_HIP(hipStreamWaitEvent(c, e_fork, 0));
+
+    // R: right-looking update of `nblk` future diagonal blocks starting at row/col j0 with panel [k0,k1)
+    auto launch_r = [&](int j0, int nrows, int k0, int pw, double* cout, int ldcout, int64_t scout,
+                        int64_t dcout, hipStream_t st) -> int {
+        sf_gemm_args g = {};
+        g.A = g.B = A + (int64_t)j0 * lda + k0;
+        g.Cin = A + (int64_t)j0 * lda + j0;
+        g.Cout = cout;
+        g.sA = g.sB = g.sCin = stride;
+        g.sCout = scout;
+        g.lda = g.ldb = g.ldcin = lda;
+        g.ldcout = ldcout;
+        g.M = g.Nc = nrows;
+        g.K = pw;
+        g.remap_after = 0x7fffffff;
+        g.diag_blocks = (nrows + SF_NB - 1) / SF_NB;
+        g.dA = (int64_t)SF_NB * lda;
+        g.dC = dcout;
+        if (rhs && pw > 0) {
+            g.rhs = rhs + j0;
+            g.z = rhs + k0;
+            g.srhs = g.sz = ldr;
+        }
+        // algorithmic flops: lower triangle of every block
+        double useful = 0.0;
+        for (int r = 0; r < nrows; r += SF_NB) {
+            const double bw = (nrows - r < SF_NB) ? nrows - r : SF_NB;
+            useful += 0.5 * bw * (bw + 1);
+        }
+        return launch_gemm(g, batch, true, 2.0 * pw * useful * batch, st);
+    };
+
+    // diagonal block 0 goes to the panel scratch unchanged (K = 0: a copy)
+    {
+        const int pw0 = n < SF_NB ? n : SF_NB;
+        SF_TRY(launch_r(0, pw0, 0, 0, T, SF_LDT, sT, 0, c));
+    }
+    int panel = 0;
+    for (int k0 = 0; k0 < n; k0 += SF_NB, ++panel) {
         const int k1 = (k0 + SF_NB < n) ? k0 + SF_NB : n;
         const int pw = k1 - k0;
-        // ---- U
-        {
+        const int nbelow = n - k1;
+        const int ntop = nbelow < SF_NB ? nbelow : SF_NB;  // rows of the next diagonal block
+        double* Wt = Wt2 + (size_t)(panel & 1) * batch * sW;
+        hipEvent_t e_ur = nullptr, e_f, e_gt;
+        // ---- Ur on the main stream: rows [k1, n) -> T rows [2pw, ...)
+        if (nbelow > 0) {
+            if (e_gt_prev) SF_HIP(hipStreamWaitEvent(s, e_gt_prev, 0));
             sf_gemm_args g = {};
-            g.A = A + (int64_t)k0 * lda;
+            g.A = A + (int64_t)k1 * lda;
             g.B = A + (int64_t)k0 * lda;
-            g.Cin = A + (int64_t)k0 * lda + k0;
-            g.Cout = T;
+            g.Cin = A + (int64_t)k1 * lda + k0;
+            g.Cout = T + (int64_t)(2 * pw) * SF_LDT;
             g.sA = g.sB = g.sCin = stride;
             g.sCout = sT;
             g.lda = g.ldb = g.ldcin = lda;
             g.ldcout = SF_LDT;
-            g.M = n - k0;
+            g.M = nbelow;
             g.Nc = pw;
             g.K = k0;
-            g.tri = 1;
-            g.remap_after = pw;
-            g.remap_shift = pw;
-            if (rhs && k0 > 0) {
-                g.rhs = rhs + k0;
-                g.z = rhs;
-                g.srhs = g.sz = ldr;
-            }
-            const double useful = (double)g.M * pw - 0.5 * (double)pw * (pw - 1);
-            int rc = launch_gemm(g, batch, true, 2.0 * k0 * useful * batch, s);
-            if (rc) return rc;
+            g.remap_after = 0x7fffffff;
+            SF_TRY(launch_gemm(g, batch, true, 2.0 * k0 * (double)nbelow * pw * batch, s));
+            SF_TRY(next_event(&e_ur));
+            SF_HIP(hipEventRecord(e_ur, s));
         }
-        // ---- D
-        hipLaunchKernelGGL(k_set_identity, dim3(16, batch), dim3(256), 0, s, T, sT, pw);
-        SF_LAUNCH_CHECK();
-        for (int c = 0; c < pw; c += SF_LEAF) {
-            hipLaunchKernelGGL(k_potrf_leaf, dim3(batch), dim3(64), 0, s, T, SF_LDT, sT, c, info, k0, ltbuf,
-                               rhs ? rhs + k0 : nullptr, ldr);
+        // ---- D + F on the side stream (T rows [0, pw) already hold the fully updated diagonal block)
+        if (fused_diag) {
+            hipLaunchKernelGGL(k_panel_diag, dim3(batch), dim3(256), 0, c, T, sT, pw, info, k0,
+                               rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
             SF_LAUNCH_CHECK();
-            const int below = 2 * pw - (c + SF_LEAF);
-            hipLaunchKernelGGL(k_trsm_leaf, dim3((below + 63) / 64, batch), dim3(64), 0, s, T, SF_LDT, sT, c,
-                               2 * pw, (const double*)ltbuf, rhs ? rhs + k0 : nullptr, ldr, pw);
+        } else {
+            hipLaunchKernelGGL(k_set_identity, dim3(64, batch), dim3(256), 0, c, T, sT, pw);
             SF_LAUNCH_CHECK();
-            if (c + SF_LEAF < pw) {
-                sf_gemm_args g = {};
-                const int o = c + SF_LEAF;
-                g.A = T + (int64_t)o * SF_LDT + c;
-                g.B = g.A;
-                g.Cin = T + (int64_t)o * SF_LDT + o;
-                g.Cout = T + (int64_t)o * SF_LDT + o;
-                g.sA = g.sB = g.sCin = g.sCout = sT;
-                g.lda = g.ldb = g.ldcin = g.ldcout = SF_LDT;
-                g.M = below;
-                g.Nc = pw - o;
-                g.K = SF_LEAF;
-                g.tri = 1;
-                g.remap_after = 0x7fffffff;
-                const double useful = (double)g.M * g.Nc - 0.5 * (double)g.Nc * (g.Nc - 1);
-                int rc = launch_gemm(g, batch, true, 2.0 * SF_LEAF * useful * batch, s);
-                if (rc) return rc;
+            for (int cc = 0; cc < pw; cc += SF_LEAF) {
+                hipLaunchKernelGGL(k_potrf_leaf, dim3(batch), dim3(64), 0, c, T, SF_LDT, sT, cc, info, k0, ltbuf,
+                                   rhs ? rhs + k0 : nullptr, ldr);
+                SF_LAUNCH_CHECK();
+                const int below = 2 * pw - (cc + SF_LEAF);
+                hipLaunchKernelGGL(k_trsm_leaf, dim3((below + 63) / 64, batch), dim3(64), 0, c, T, SF_LDT, sT,
+                                   cc, 2 * pw, (const double*)ltbuf, rhs ? rhs + k0 : nullptr, ldr, pw);
+                SF_LAUNCH_CHECK();
+                if (cc + SF_LEAF < pw) {
+                    sf_gemm_args g = {};
+                    const int o = cc + SF_LEAF;
+                    g.A = g.B = T + (int64_t)o * SF_LDT + cc;
+                    g.Cin = g.Cout = T + (int64_t)o * SF_LDT + o;
+                    g.sA = g.sB = g.sCin = g.sCout = sT;
+                    g.lda = g.ldb = g.ldcin = g.ldcout = SF_LDT;
+                    g.M = below;
+                    g.Nc = pw - o;
+                    g.K = SF_LEAF;
+                    g.tri = 1;
+                    g.remap_after = 0x7fffffff;
+                    const double useful = (double)g.M * g.Nc - 0.5 * (double)g.Nc * (g.Nc - 1);
+                    SF_TRY(launch_gemm(g, batch, true, 2.0 * SF_LEAF * useful * batch, c));
+                }
             }
+            hipLaunchKernelGGL(k_panel_finish, dim3((pw + 31) / 32, (pw + 31) / 32, batch), dim3(256), 0, c,
+                               (const double*)T, sT, pw, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
+            SF_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(k_panel_finish, dim3((pw + 31) / 32, (pw + 31) / 32, batch), dim3(256), 0, s,
-                           (const double*)T, sT, pw, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
-        SF_LAUNCH_CHECK();
-        // ---- G
-        if (n > k1) {
+        if (nbelow <= 0) break;
+        SF_TRY(next_event(&e_f));
+        SF_HIP(hipEventRecord(e_f, c));
+        // ---- G: T[below] W.  Top rows (next diagonal block) on the side stream, the rest on main.
+        auto launch_g = [&](int row_lo, int nrows, hipStream_t st) -> int {
             sf_gemm_args g = {};
-            g.A = T + (int64_t)(2 * pw) * SF_LDT;
+            g.A = T + (int64_t)(2 * pw + row_lo) * SF_LDT;
             g.B = Wt;
-            g.Cin = nullptr;
-            g.Cout = A + (int64_t)k1 * lda + k0;
+            g.Cout = A + (int64_t)(k1 + row_lo) * lda + k0;
             g.sA = sT;
             g.sB = sW;
             g.sCout = stride;
             g.lda = g.ldb = SF_LDT;
             g.ldcout = lda;
-            g.M = n - k1;
+            g.M = nrows;
             g.Nc = pw;
             g.K = pw;
             g.btri = 1;
             g.remap_after = 0x7fffffff;
-            int rc = launch_gemm(g, batch, false, (double)g.M * pw * pw * batch, s);
-            if (rc) return rc;
+            return launch_gemm(g, batch, false, (double)nrows * pw * pw * batch, st);
+        };
+        SF_HIP(hipStreamWaitEvent(c, e_ur, 0));
+        SF_TRY(launch_g(0, ntop, c));
+        SF_TRY(next_event(&e_gt));
+        SF_HIP(hipEventRecord(e_gt, c));
+        e_gt_prev = e_gt;
+        // next diagonal block: apply this panel's columns and park it in the panel scratch
+        SF_TRY(launch_r(k1, ntop, k0, pw, T, SF_LDT, sT, 0, c));
+        if (nbelow > ntop) {
+            SF_HIP(hipStreamWaitEvent(s, e_f, 0));
+            SF_TRY(launch_g(ntop, nbelow - ntop, s));
+            // the diagonal blocks after the next one are updated in place
+            const int j0 = k1 + ntop;
+            SF_TRY(launch_r(j0, n - j0, k0, pw, A + (int64_t)j0 * lda + j0, lda, stride,
+                            (int64_t)SF_NB * lda + SF_NB, s));
         }
     }
+    // join: the caller's stream continues only after the side chain is done
+    hipEvent_t e_join;
+    SF_TRY(next_event(&e_join));
+    SF_HIP(hipEventRecord(e_join, c));
+    SF_HIP(hipStreamWaitEvent(s, e_join, 0));
     return SF_OK;
 }
 

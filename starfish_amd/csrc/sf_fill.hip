@@ -44,9 +44,11 @@ __device__ __forceinline__ double sf_local_metric(double w, double mu) {
     return SF_C_KMS / mu * fabs(w - mu);  // kernels.py:69
 }
 
-#define SF_MAX_LOCAL 8
+#define SF_MAX_LOCAL 32
 
-__global__ __launch_bounds__(256) void k_fill(sf_fill_args a, int nt) {
+// Pass 1 (every stored tile): rank-m term on MFMA + sigma^2 on the diagonal + identity padding.
+// Lean on registers so that many waves hide the store latency (the pass is HBM-write bound).
+__global__ __launch_bounds__(256, 4) void k_fill_plain(sf_fill_args a, int nt, int jitter_here) {
     const int id = sf_xcd_remap_f(blockIdx.x, gridDim.x);
     const int tiles = nt * nt;
     const int b = id / tiles;
@@ -62,10 +64,9 @@ __global__ __launch_bounds__(256) void k_fill(sf_fill_args a, int nt) {
     const int gam = lane & 15, q = lane >> 4;
 
     const double* __restrict__ Yb = a.Y + (int64_t)b * a.mpad * a.ldy;
-    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
     double* __restrict__ Cb = a.C + (int64_t)b * a.stride;
 
-    // ---- rank-m term: acc[ti][tj] element (row R0+ti*16+gam, cols C0+tj*16+4q+r)
+    // acc[ti][tj] element (row R0+ti*16+gam, cols C0+tj*16+4q+r)
     sf_d4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -87,114 +88,10 @@ __global__ __launch_bounds__(256) void k_fill(sf_fill_args a, int nt) {
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[j], brow[i], acc[i][j], 0, 0, 0);
     }
 
-    // ---- which structured kernels touch this 32 x 32 sub-tile (wave-uniform decisions)
-    const int rlo = R0, rhi = min(R0 + 31, a.n - 1);
-    const int clo = C0, chi = min(C0 + 31, a.n - 1);
-    const bool real_tile = (R0 < a.n) && (C0 < a.n);
-    bool do_glob = false;
-    double g_amp = 0, g_ls = 1, g_r0 = 0;
-    if (a.has_global && real_tile) {
-        g_amp = exp(P[a.off_global]);      // spectrum_model.py:343
-        g_ls = exp(P[a.off_global + 1]);   // spectrum_model.py:344
-        g_r0 = 6 * g_ls;                   // kernels.py:29
-        do_glob = true;
-        if (a.monotonic) {
-            // closest (row, col) pair of the sub-tile in wavelength
-            double wr, wc;
-            if (rlo > chi) { wr = a.wave[rlo]; wc = a.wave[chi]; }
-            else if (clo > rhi) { wr = a.wave[rhi]; wc = a.wave[clo]; }
-            else { wr = wc = 1.0; }
-            const double rmin = SF_C_KMS / 2 * fabs((wc - wr) / (wc + wr));
-            do_glob = rmin <= g_r0 * (1 + 1e-9);
-        }
-    }
-    // ---- epilogue: structured terms in the reference's order of additions, then store
     const bool vec_ok = (a.lda & 1) == 0;
-    int rows[2];
-    double w_rows[2];
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
-        rows[ti] = R0 + ti * 16 + gam;
-        w_rows[ti] = (rows[ti] < a.n) ? a.wave[rows[ti]] : 1.0;
-    }
-    double w_cols[2][4];
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = C0 + tj * 16 + 4 * q + r;
-            w_cols[tj][r] = (col < a.n) ? a.wave[col] : 1.0;
-        }
-
-    if (real_tile) {
-        // spectrum_model.py:338  diagonal noise, then :348 global kernel
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rows[ti], col = C0 + tj * 16 + 4 * q + r;
-                    if (row < a.n && col < a.n) {
-                        double val = acc[ti][tj][r];
-                        if (row == col) {
-                            const double sg = a.sigma[row];
-                            val = val + sg * sg;
-                        }
-                        if (do_glob)
-                            val = val + sf_matern_elem(w_rows[ti], w_cols[tj][r], g_amp, g_ls, g_r0);
-                        acc[ti][tj][r] = val;
-                    }
-                }
-        // spectrum_model.py:353-363  _loc_cov = 0 + K_0 + K_1 + ... ; cov += _loc_cov
-        if (a.n_local > 0) {
-            sf_d4 loc[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) loc[i][j] = (sf_d4){0.0, 0.0, 0.0, 0.0};
-            bool any = false;
-            for (int k = 0; k < a.n_local; ++k) {
-                const double mu = P[a.off_local + 3 * k];
-                const double amp = exp(P[a.off_local + 3 * k + 1]);  // spectrum_model.py:356
-                const double sig = exp(P[a.off_local + 3 * k + 2]);  // spectrum_model.py:357
-                const double r0 = 4 * sig;                           // kernels.py:73
-                bool hit = true;
-                if (a.monotonic) {
-                    // smallest metric inside an index range is at the ends or across mu
-                    auto dmin = [&](int lo, int hi) {
-                        const double wl = a.wave[lo], wh = a.wave[hi];
-                        if (wl <= mu && mu <= wh) return 0.0;
-                        return fmin(sf_local_metric(wl, mu), sf_local_metric(wh, mu));
-                    };
-                    hit = (dmin(rlo, rhi) <= r0 * (1 + 1e-9)) && (dmin(clo, chi) <= r0 * (1 + 1e-9));
-                }
-                if (!hit) continue;
-                any = true;
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti) {
-                    const double d_row = sf_local_metric(w_rows[ti], mu);
-#pragma unroll
-                    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            loc[ti][tj][r] = loc[ti][tj][r] +
-                                             sf_local_elem(d_row, sf_local_metric(w_cols[tj][r], mu), amp,
-                                                           sig, r0);
-                }
-            }
-            if (any) {
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = acc[ti][tj] + loc[ti][tj];
-            }
-        }
-    }
-
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int row = rows[ti];
+        const int row = R0 + ti * 16 + gam;
         if (row >= nout) continue;
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
@@ -206,7 +103,11 @@ __global__ __launch_bounds__(256) void k_fill(sf_fill_args a, int nt) {
                 const int col = col0 + r;
                 double val = acc[ti][tj][r];
                 if (row < a.n && col < a.n) {
-                    if (row == col && a.add_jitter) val = val + SF_JITTER;  // spectrum_model.py:399
+                    if (row == col) {
+                        const double sg = a.sigma[row];
+                        val = val + sg * sg;                                     // spectrum_model.py:338
+                        if (jitter_here && a.add_jitter) val = val + SF_JITTER;  // spectrum_model.py:399
+                    }
                 } else {
                     val = (row == col) ? 1.0 : 0.0;  // identity padding up to the Cholesky leaf
                 }
@@ -225,6 +126,109 @@ __global__ __launch_bounds__(256) void k_fill(sf_fill_args a, int nt) {
     }
 }
 
+// Pass 2 (only sub-tiles that intersect the support of a structured kernel, everything else exits at
+// once): C += K_global, then C += (0 + K_local,0 + K_local,1 ...), then the jitter -- the reference's
+// order of additions (spectrum_model.py:348, 353-363, 399).
+__global__ __launch_bounds__(256) void k_fill_band(sf_fill_args a, int nt) {
+    const int id = sf_xcd_remap_f(blockIdx.x, gridDim.x);
+    const int tiles = nt * nt;
+    const int b = id / tiles;
+    const int t = id - b * tiles;
+    const int tm = t / nt, tn = t - tm * nt;
+    if (a.lower_only && tn > tm) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
+    if (R0 >= a.n || C0 >= a.n) return;
+    if (a.lower_only && C0 > R0 + 31) return;
+    const int gam = lane & 15, q = lane >> 4;
+    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
+    double* __restrict__ Cb = a.C + (int64_t)b * a.stride;
+
+    const int rlo = R0, rhi = min(R0 + 31, a.n - 1);
+    const int clo = C0, chi = min(C0 + 31, a.n - 1);
+    const bool on_diag = !(rlo > chi || clo > rhi);
+    bool do_glob = false;
+    double g_amp = 0, g_ls = 1, g_r0 = 0;
+    if (a.has_global) {
+        g_amp = exp(P[a.off_global]);      // spectrum_model.py:343
+        g_ls = exp(P[a.off_global + 1]);   // spectrum_model.py:344
+        g_r0 = 6 * g_ls;                   // kernels.py:29
+        do_glob = true;
+        if (a.monotonic && !on_diag) {
+            // closest (row, col) pair of the sub-tile in wavelength
+            double wr, wc;
+            if (rlo > chi) { wr = a.wave[rlo]; wc = a.wave[chi]; }
+            else { wr = a.wave[rhi]; wc = a.wave[clo]; }
+            const double rmin = SF_C_KMS / 2 * fabs((wc - wr) / (wc + wr));
+            do_glob = rmin <= g_r0 * (1 + 1e-9);
+        }
+    }
+    unsigned lmask = 0;
+    for (int k = 0; k < a.n_local; ++k) {
+        bool hit = true;
+        if (a.monotonic) {
+            const double mu = P[a.off_local + 3 * k];
+            const double r0 = 4 * exp(P[a.off_local + 3 * k + 2]);  // kernels.py:73
+            auto dmin = [&](int lo, int hi) {  // smallest metric over an index range
+                const double wl = a.wave[lo], wh = a.wave[hi];
+                if (wl <= mu && mu <= wh) return 0.0;
+                return fmin(sf_local_metric(wl, mu), sf_local_metric(wh, mu));
+            };
+            hit = (dmin(rlo, rhi) <= r0 * (1 + 1e-9)) && (dmin(clo, chi) <= r0 * (1 + 1e-9));
+        }
+        if (hit) lmask |= 1u << k;
+    }
+    const bool jitter = a.add_jitter && on_diag;
+    if (!do_glob && !lmask && !jitter) return;
+
+    const bool vec_ok = (a.lda & 1) == 0;
+    for (int ti = 0; ti < 2; ++ti) {
+        const int row = R0 + ti * 16 + gam;
+        if (row >= a.n) continue;
+        const double w_row = a.wave[row];
+        for (int tj = 0; tj < 2; ++tj) {
+            const int col0 = C0 + tj * 16 + 4 * q;
+            if (col0 >= a.n) continue;
+            double* dst = Cb + (int64_t)row * a.lda + col0;
+            const bool vec = vec_ok && col0 + 3 < a.n;
+            double v[4];
+            if (vec) {
+                const double2 p0 = *(const double2*)dst, p1 = *(const double2*)(dst + 2);
+                v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
+            } else {
+                for (int r = 0; r < 4; ++r) v[r] = (col0 + r < a.n) ? dst[r] : 0.0;
+            }
+            double w_col[4];
+            for (int r = 0; r < 4; ++r) w_col[r] = (col0 + r < a.n) ? a.wave[col0 + r] : 1.0;
+            if (do_glob)
+                for (int r = 0; r < 4; ++r) v[r] = v[r] + sf_matern_elem(w_row, w_col[r], g_amp, g_ls, g_r0);
+            if (lmask) {
+                double loc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int k = 0; k < a.n_local; ++k) {
+                    if (!((lmask >> k) & 1)) continue;
+                    const double mu = P[a.off_local + 3 * k];
+                    const double amp = exp(P[a.off_local + 3 * k + 1]);  // spectrum_model.py:356
+                    const double sig = exp(P[a.off_local + 3 * k + 2]);  // spectrum_model.py:357
+                    const double d_row = sf_local_metric(w_row, mu);
+                    for (int r = 0; r < 4; ++r)
+                        loc[r] = loc[r] + sf_local_elem(d_row, sf_local_metric(w_col[r], mu), amp, sig, 4 * sig);
+                }
+                for (int r = 0; r < 4; ++r) v[r] = v[r] + loc[r];
+            }
+            if (jitter)
+                for (int r = 0; r < 4; ++r)
+                    if (col0 + r == row) v[r] = v[r] + SF_JITTER;  // spectrum_model.py:399
+            if (vec) {
+                *(double2*)dst = make_double2(v[0], v[1]);
+                *(double2*)(dst + 2) = make_double2(v[2], v[3]);
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (col0 + r < a.n) dst[r] = v[r];
+            }
+        }
+    }
+}
+
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
     if (a.n_local > SF_MAX_LOCAL) {
         sf_set_error("at most %d local kernels are supported", SF_MAX_LOCAL);
@@ -237,8 +241,13 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
         sf_set_error("fill grid too large");
         return SF_EINVAL;
     }
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)nblk), dim3(256), 0, s, a, nt);
+    const int structured = a.has_global || a.n_local > 0;
+    hipLaunchKernelGGL(k_fill_plain, dim3((unsigned)nblk), dim3(256), 0, s, a, nt, structured ? 0 : 1);
     SF_LAUNCH_CHECK();
+    if (structured) {
+        hipLaunchKernelGGL(k_fill_band, dim3((unsigned)nblk), dim3(256), 0, s, a, nt);
+        SF_LAUNCH_CHECK();
+    }
     return SF_OK;
 }
 

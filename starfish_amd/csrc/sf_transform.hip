@@ -163,33 +163,26 @@ __global__ __launch_bounds__(256) void k_rfft_rows(const double* __restrict__ in
 // ------------------------------------------------------------------------- banded spline solve
 // One lane per right-hand side; element j of system s lives at data[s_base(s) + j*estride].
 // Systems are grouped: s = b*rows + r -> base = b*bstride + r*rstride.
-// The recurrences are sequential in j, so the loads are software-pipelined: the values of the NEXT
-// chunk of SCH rows are in flight while the current chunk is eliminated, and the (lane-uniform)
-// factor rows of a chunk are staged in LDS by the whole wave.
-#define SCH 32
+// The recurrences are sequential in j and only ~20 waves exist (B*(m+2)/64), so the kernel is pure
+// latency: every lane keeps the NEXT chunk of SCH rows (and lane l the factor row j0+l) in flight in
+// registers while the current chunk is eliminated; factor rows are broadcast through LDS.
+#define SCH 64
 __global__ __launch_bounds__(64) void k_spline_solve(double* __restrict__ data, int nsys, int rows,
                                                      int64_t bstride, int64_t rstride, int64_t estride,
                                                      int n, const double* __restrict__ Lf,
                                                      const double* __restrict__ Uf,
                                                      const double* __restrict__ rdiag) {
-    __shared__ double fac[2][SCH * (SF_KB + 1)];
+    __shared__ double fac[SCH * (SF_KB + 1)];
     const int lane = threadIdx.x;
     int s = blockIdx.x * 64 + lane;
     const bool live = s < nsys;
-    if (!live) s = nsys - 1;  // keep the wave converged for the LDS staging; results are not stored
+    if (!live) s = nsys - 1;  // keep the wave converged; results of dead lanes are not stored
     const int b = s / rows, r = s - b * rows;
     double* x = data + (int64_t)b * bstride + (int64_t)r * rstride;
     const int nch = (n + SCH - 1) / SCH;
 
     double cur[SCH], nxt[SCH];
-    // ---------------- forward: y_j = b_j - sum_{k=1..KB} L[j][k] y_{j-k}
-    auto stage_fwd = [&](int ch, int buf) {
-        const int j0 = ch * SCH;
-        for (int e = lane; e < SCH * SF_KB; e += 64) {
-            const int jj = e / SF_KB, k = e - jj * SF_KB;
-            fac[buf][jj * (SF_KB + 1) + k] = (j0 + jj < n) ? Lf[(int64_t)(j0 + jj) * SF_KB + k] : 0.0;
-        }
-    };
+    double cf[SF_KB + 1], nf[SF_KB + 1];
     auto load_chunk = [&](int ch, double* v) {
         const int j0 = ch * SCH;
 #pragma unroll
@@ -202,19 +195,32 @@ __global__ __launch_bounds__(64) void k_spline_solve(double* __restrict__ data, 
         for (int jj = 0; jj < SCH; ++jj)
             if (j0 + jj < n) x[(int64_t)(j0 + jj) * estride] = v[jj];
     };
+    auto load_fac = [&](int ch, const double* __restrict__ F, bool with_diag, double* f) {
+        const int j = ch * SCH + lane;
+#pragma unroll
+        for (int k = 0; k < SF_KB; ++k) f[k] = (j < n) ? F[(int64_t)j * SF_KB + k] : 0.0;
+        f[SF_KB] = (with_diag && j < n) ? rdiag[j] : 0.0;
+    };
+    auto publish_fac = [&](const double* f) {
+        __syncthreads();  // everyone finished reading the previous chunk's factors
+#pragma unroll
+        for (int k = 0; k <= SF_KB; ++k) fac[lane * (SF_KB + 1) + k] = f[k];
+        __syncthreads();
+    };
+
+    // ---------------- forward: y_j = b_j - sum_{k=1..KB} L[j][k] y_{j-k}
     double y1 = 0, y2 = 0, y3 = 0, y4 = 0, y5 = 0;
+    load_fac(0, Lf, false, cf);
     load_chunk(0, cur);
-    stage_fwd(0, 0);
-    __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
-        const int buf = ch & 1;
+        publish_fac(cf);
         if (ch + 1 < nch) {
+            load_fac(ch + 1, Lf, false, nf);
             load_chunk(ch + 1, nxt);
-            stage_fwd(ch + 1, buf ^ 1);
         }
 #pragma unroll
         for (int jj = 0; jj < SCH; ++jj) {
-            const double* l = &fac[buf][jj * (SF_KB + 1)];
+            const double* l = &fac[jj * (SF_KB + 1)];
             // older terms first (off the critical path); the dependent step is a single fma
             const double part = cur[jj] - ((l[4] * y5 + l[3] * y4) + (l[2] * y3 + l[1] * y2));
             const double v = fma(-l[0], y1, part);
@@ -224,33 +230,25 @@ __global__ __launch_bounds__(64) void k_spline_solve(double* __restrict__ data, 
         store_chunk(ch, cur);
 #pragma unroll
         for (int jj = 0; jj < SCH; ++jj) cur[jj] = nxt[jj];
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k <= SF_KB; ++k) cf[k] = nf[k];
     }
     // ---------------- backward: c_j = (y_j - sum_{k=1..KB} U[j][k] c_{j+k}) / U[j][j]
-    auto stage_bwd = [&](int ch, int buf) {
-        const int j0 = ch * SCH;
-        for (int e = lane; e < SCH * (SF_KB + 1); e += 64) {
-            const int jj = e / (SF_KB + 1), k = e - jj * (SF_KB + 1);
-            double v = 0.0;
-            if (j0 + jj < n) v = (k < SF_KB) ? Uf[(int64_t)(j0 + jj) * SF_KB + k] : rdiag[j0 + jj];
-            fac[buf][e] = v;
-        }
-    };
     double c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    __threadfence_block();
+    load_fac(nch - 1, Uf, true, cf);
     load_chunk(nch - 1, cur);
-    stage_bwd(nch - 1, 0);
-    __syncthreads();
-    for (int ch = nch - 1, it = 0; ch >= 0; --ch, ++it) {
-        const int buf = it & 1;
+    for (int ch = nch - 1; ch >= 0; --ch) {
+        publish_fac(cf);
         if (ch > 0) {
+            load_fac(ch - 1, Uf, true, nf);
             load_chunk(ch - 1, nxt);
-            stage_bwd(ch - 1, buf ^ 1);
         }
         const int j0 = ch * SCH;
 #pragma unroll
         for (int jj = SCH - 1; jj >= 0; --jj) {
             if (j0 + jj < n) {
-                const double* u = &fac[buf][jj * (SF_KB + 1)];
+                const double* u = &fac[jj * (SF_KB + 1)];
                 const double part = (cur[jj] - ((u[4] * c5 + u[3] * c4) + (u[2] * c3 + u[1] * c2))) * u[SF_KB];
                 const double v = fma(-(u[0] * u[SF_KB]), c1, part);
                 cur[jj] = v;
@@ -260,7 +258,8 @@ __global__ __launch_bounds__(64) void k_spline_solve(double* __restrict__ data, 
         store_chunk(ch, cur);
 #pragma unroll
         for (int jj = 0; jj < SCH; ++jj) cur[jj] = nxt[jj];
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k <= SF_KB; ++k) cf[k] = nf[k];
     }
 }
 
