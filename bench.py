@@ -101,6 +101,17 @@ def main():
     assert np.isfinite(lnl_host).all()
 
     if rank == 0:
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 as
+        # the micro-arch guide prescribes for gfx950, + WRITE_SIZE), summarised under profiles/ by
+        # tools/summarize_profile.py; bench.py cannot collect counters itself.
+        import glob
+
+        traffic, traffic_src = None, None
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))[-1:]:
+            if N == 4096 and B == 128:
+                with open(f) as fh:
+                    traffic = json.load(fh)["_k_gemm_nt_all"]["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(f, ROOT)
         gemm_s = ms[2] * 1e-3
         achieved = gflops.value / gemm_s / 1e12 if gemm_s > 0 else 0.0
         flops_eval = N**3 / 3 + 2 * 8 * N**2 + N**2
@@ -131,15 +142,19 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "note": "k_gemm_nt launches run on two streams (lookahead) and overlap each other: the sum of "
+                "their launch durations exceeds the wall time of the Cholesky stage",
                 "launches": int(glaunch.value),
                 "avg_launch_ms": ms[2] / max(1, glaunch.value),
                 "algorithmic_flops_per_launch": gflops.value / max(1, glaunch.value),
             },
             "stage_ms_per_step": {
                 k: v / max(1, args.steps)
-                for k, v in zip(["transforms", "fill", "gemm", "potrf_total", "solve"], ms)
+                for k, v in zip(["transforms", "fill", "gemm_launches_sum", "potrf_stage", "solve"], ms)
             },
+            "potrf_stage_tflops": B * args.steps * (N**3 / 3) / (ms[3] * 1e-3) / 1e12 if ms[3] > 0 else None,
         }
         if world == 1 and args.cpu_sample > 0:
             from oracle import sf_oracle as O
