@@ -154,3 +154,52 @@ def test_wasp14_order_plumbing():
     assert out["info"][0] == 0
     assert close_lnl(out["lnl"][0], g["lnl"][0])
     assert close_lnl(O.log_likelihood(oo, p), g["lnl"][0])
+
+
+def test_cfg2_full_size_n4096_vs_reference():
+    """BASELINE config 2 at full size: the reference's own values (tools/gen_golden.py --big)."""
+    g = load_golden("model_cfg2.npz")
+    o = synth.make_order(N=4096)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    P = g["n4096_batch_P"]
+    plist = [synth.vector_to_oracle_params(synth.centre_vector(o))] + [synth.vector_to_oracle_params(p) for p in P]
+    md, rows = pack_rows(do, plist)
+    out = do.loglike(md, rows)
+    assert (out["info"] == 0).all()
+    assert close_lnl(out["lnl"][0], g["n4096_lnl"][0])
+    assert abs(out["lnl"][0] - 16579.1706341206) < 1e-6  # SURVEY.md section 8c known answer
+    assert abs(out["logdet"][0] - g["n4096_lnl"][1]) <= 1e-10 * abs(g["n4096_lnl"][1])
+    assert abs(out["sqmah"][0] - g["n4096_lnl"][2]) <= 1e-8 * abs(g["n4096_lnl"][2])
+    for b in range(len(P)):
+        assert close_lnl(out["lnl"][1 + b], g["n4096_batch_lnl"][b])
+    # size-independent properties at full size: replicas agree bit for bit, order in the batch is irrelevant
+    rep = do.loglike(md, np.repeat(rows[:2], 3, axis=0))
+    assert rep["lnl"][0] == rep["lnl"][1] == rep["lnl"][2] == out["lnl"][0]
+    assert rep["lnl"][3] == rep["lnl"][4] == rep["lnl"][5] == out["lnl"][1]
+    fw = do.forward(md, rows[:1])
+    cov = fw["cov"][0]
+    np.testing.assert_allclose(cov.diagonal(), g["n4096_diag"], rtol=1e-10)
+    np.testing.assert_allclose(cov[g["n4096_ii"], g["n4096_jj"]], g["n4096_vals"], rtol=1e-10,
+                               atol=1e-11 * np.abs(g["n4096_diag"]).max())
+    np.testing.assert_allclose(fw["flux"][0], g["n4096_flux"], rtol=0, atol=1e-10)
+
+
+def test_cfg5_long_order_n16384_vs_reference():
+    """BASELINE config 5 (N = 16384, N_f = 32768: FFT through the global-memory path) against the value
+    produced by the real reference."""
+    g = load_golden("model_cfg5.npz")
+    o = synth.make_order(N=16384)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    assert do.nf == 32768
+    p = synth.vector_to_oracle_params(synth.centre_vector(o))
+    md, rows = pack_rows(do, [p, p])
+    out = do.loglike(md, rows, want_resid=True)
+    assert (out["info"] == 0).all()
+    ref = g["n16384_lnl"]
+    assert close_lnl(out["lnl"][0], ref[0]) and out["lnl"][0] == out["lnl"][1]
+    assert abs(out["lnl"][0] - 66263.72856408486) < 1e-5
+    assert abs(out["logdet"][0] - ref[1]) <= 1e-10 * abs(ref[1])
+    assert abs(out["sqmah"][0] - ref[2]) <= 1e-8 * abs(ref[2])
+    np.testing.assert_allclose(out["resid"][0], g["n16384_flux"] - oo.flux, rtol=0, atol=1e-10)
