@@ -21,6 +21,13 @@
  *     <0 = SF_INFO_* (parameter outside the emulator grid, non-positive vsini, ...).
  *   - all matrices are row-major; the Cholesky factor is the LOWER triangle (A = L L^T), the strict
  *     upper triangle is not referenced.
+ *   - the batched Cholesky forks part of its launches onto a library-owned side stream (lookahead) and
+ *     joins it back to `stream` with an event before returning: from the caller's point of view all
+ *     work is ordered on `stream`.  The library keeps process-global state (side stream, event pool,
+ *     timing hooks): issue calls from ONE host thread per process (one process per GPU).
+ *   - environment switches (tuning aids, read once): SF_NO_LOOKAHEAD=1 single-stream Cholesky,
+ *     SF_FUSED_DIAG=1 one-launch diagonal-block step, SF_GEMM_256=1 / SF_GEMM_1024=1 alternative
+ *     wave layouts of the MFMA update kernel (default: 512 threads, measured fastest).
  */
 #ifndef STARFISH_AMD_H
 #define STARFISH_AMD_H

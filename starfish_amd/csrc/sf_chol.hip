@@ -65,8 +65,15 @@ struct sf_gemm_args {
 // SIMD reach one per ~100 cycles, four waves per SIMD saturate the 64-cycle pipe.  The kernel is
 // therefore built for 4 waves/SIMD: 512 threads (8 waves, each 32 x 64 of the 128 x 128 tile = 2 x 4
 // MFMA tiles = 64 accumulator VGPRs), <= 128 VGPRs, two workgroups per CU.
-template <bool NEG, bool RHS>
-__global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
+// Wave layout: WN waves across the 128 columns, 128/(16*TM) ... the tile is always 128 x 128;
+// NTH = 512 -> 8 waves of 32 x 64 (TM=2, TN=4);  NTH = 1024 -> 16 waves of 32 x 32 (TM=2, TN=2).
+template <bool NEG, bool RHS, int NTH>
+__global__ __launch_bounds__(NTH, (NTH == 256) ? 2 : NTH / 128) void k_gemm_nt(sf_gemm_args g) {
+    constexpr int TM = (NTH == 256) ? 4 : 2;
+    constexpr int TN = (NTH == 1024) ? 2 : 4;
+    constexpr int WN = 128 / (16 * TN);   // waves across columns
+    constexpr int NP = 1024 / NTH;        // staging passes of NTH/8 rows each
+    constexpr int RPP = NTH / 8;          // rows per staging pass
     __shared__ __attribute__((aligned(16))) double As[2][GT * GLD];
     __shared__ __attribute__((aligned(16))) double Bs[2][GT * GLD];
 
@@ -102,20 +109,20 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;  // 4 x 2 waves: rows wm*32.., cols wn*64..
+    const int wm = w / WN, wn = w % WN;  // rows wm*32.., cols wn*(16*TN)..
     const int l15 = lane & 15, lq = lane >> 4;
 
     // ---- accumulators start as the C tile
-    sf_d4 acc[2][4];
+    sf_d4 acc[TM][TN];
     const double* Cin = g.Cin ? g.Cin + (int64_t)b * g.sCin + (int64_t)row0 * g.ldcin + col0 : nullptr;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int col = wn * 64 + ni * 16 + l15;
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = wn * (16 * TN) + ni * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wm * 32 + mi * 16 + lq + 4 * r;
+                const int row = wm * (16 * TM) + mi * 16 + lq + 4 * r;
                 double v = 0.0;
                 if (Cin && row < rows_here && col < cols_here) v = Cin[(int64_t)row * g.ldcin + col];
                 acc[mi][ni][r] = v;
@@ -127,22 +134,24 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
     // duplicated data only feeds accumulator rows / columns that are never stored, and the loads stay
     // branch-free (a predicated load makes hipcc wait for the whole vm queue).
     const int lr = tid >> 3, lc = (tid & 7) * 2;
-    const double* Ap[2];
-    const double* Bp[2];
+    const double* Ap[NP];
+    const double* Bp[NP];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        Ap[p] = g.A + (int64_t)b * g.sA + (int64_t)(row0 + min(lr + 64 * p, rows_here - 1)) * g.lda + lc;
-        Bp[p] = g.B + (int64_t)b * g.sB + (int64_t)(col0 + min(lr + 64 * p, cols_here - 1)) * g.ldb + lc;
+    for (int p = 0; p < NP; ++p) {
+        Ap[p] = g.A + (int64_t)b * g.sA + (int64_t)(row0 + min(lr + RPP * p, rows_here - 1)) * g.lda + lc;
+        Bp[p] = g.B + (int64_t)b * g.sB + (int64_t)(col0 + min(lr + RPP * p, cols_here - 1)) * g.ldb + lc;
     }
-    double2 ra[2], rb[2];
+    double2 ra[NP], rb[NP];
     const bool do_rhs = RHS && g.rhs && (tm == tn);
     const double* zg = do_rhs ? g.z + (int64_t)b * g.sz + lc : nullptr;
     double2 zv = make_double2(0.0, 0.0);
-    double part[2] = {0.0, 0.0};
+    double part[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) part[p] = 0.0;
 
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NP; ++p) {
             ra[p] = *(const double2*)(Ap[p] + kt * GK);
             rb[p] = *(const double2*)(Bp[p] + kt * GK);
         }
@@ -150,9 +159,9 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            double* pa = &As[buf][(lr + 64 * p) * GLD + lc];
-            double* pb = &Bs[buf][(lr + 64 * p) * GLD + lc];
+        for (int p = 0; p < NP; ++p) {
+            double* pa = &As[buf][(lr + RPP * p) * GLD + lc];
+            double* pb = &Bs[buf][(lr + RPP * p) * GLD + lc];
             pa[0] = ra[p].x;
             pa[1] = ra[p].y;
             pb[0] = rb[p].x;
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
         }
         if (RHS && do_rhs) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) part[p] += rb[p].x * zv.x + rb[p].y * zv.y;
+            for (int p = 0; p < NP; ++p) part[p] += rb[p].x * zv.x + rb[p].y * zv.y;
         }
     };
 
@@ -172,19 +181,19 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
     __syncthreads();
 
     auto compute = [&](int cur) {
-        const double* Ab = &As[cur][(wm * 32 + l15) * GLD + lq];
-        const double* Bb = &Bs[cur][(wn * 64 + l15) * GLD + lq];
+        const double* Ab = &As[cur][(wm * (16 * TM) + l15) * GLD + lq];
+        const double* Bb = &Bs[cur][(wn * (16 * TN) + l15) * GLD + lq];
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
-            double a[2], bb[4];
+            double a[TM], bb[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = NEG ? -Ab[i * 16 * GLD + ks * 4] : Ab[i * 16 * GLD + ks * 4];
+            for (int i = 0; i < TM; ++i) a[i] = NEG ? -Ab[i * 16 * GLD + ks * 4] : Ab[i * 16 * GLD + ks * 4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bb[i] = Bb[i * 16 * GLD + ks * 4];
+            for (int i = 0; i < TN; ++i) bb[i] = Bb[i * 16 * GLD + ks * 4];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < TN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
         }
     };
@@ -200,13 +209,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
 
     double* Cout = g.Cout + (int64_t)b * g.sCout + col0;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int col = wn * 64 + ni * 16 + l15;
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = wn * (16 * TN) + ni * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wm * 32 + mi * 16 + lq + 4 * r;
+                const int row = wm * (16 * TM) + mi * 16 + lq + 4 * r;
                 if (row < rows_here && col < cols_here) {
                     int orow = row0 + row;
                     if (orow >= g.remap_after) orow += g.remap_shift;
@@ -219,12 +228,12 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt(sf_gemm_args g) {
         // the 8 threads sharing lr cover the 16 k-columns of a slab: fold them, one of them commits
         double* rhs = g.rhs + (int64_t)b * g.srhs + col0;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NP; ++p) {
             double v = part[p];
             v += __shfl_xor(v, 1);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 4);
-            const int rr = lr + 64 * p;
+            const int rr = lr + RPP * p;
             if ((tid & 7) == 0 && rr < cols_here) rhs[rr] -= v;
         }
     }
@@ -438,12 +447,30 @@ static int launch_gemm(sf_gemm_args g, int batch, bool neg, double flops, hipStr
     }
     void* tok;
     sf_prof_gemm_begin(s, flops, &tok);
-    if (g.rhs)
-        hipLaunchKernelGGL((k_gemm_nt<true, true>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else if (neg)
-        hipLaunchKernelGGL((k_gemm_nt<true, false>), dim3((unsigned)nblk), dim3(512), 0, s, g);
-    else
-        hipLaunchKernelGGL((k_gemm_nt<false, false>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+    static const bool big = getenv("SF_GEMM_1024") != nullptr;  // tuning aid: 16 waves of 32 x 32
+    static const bool small = getenv("SF_GEMM_256") != nullptr;  // tuning aid: 4 waves of 64 x 64
+    if (small) {
+        if (g.rhs)
+            hipLaunchKernelGGL((k_gemm_nt<true, true, 256>), dim3((unsigned)nblk), dim3(256), 0, s, g);
+        else if (neg)
+            hipLaunchKernelGGL((k_gemm_nt<true, false, 256>), dim3((unsigned)nblk), dim3(256), 0, s, g);
+        else
+            hipLaunchKernelGGL((k_gemm_nt<false, false, 256>), dim3((unsigned)nblk), dim3(256), 0, s, g);
+    } else if (big) {
+        if (g.rhs)
+            hipLaunchKernelGGL((k_gemm_nt<true, true, 1024>), dim3((unsigned)nblk), dim3(1024), 0, s, g);
+        else if (neg)
+            hipLaunchKernelGGL((k_gemm_nt<true, false, 1024>), dim3((unsigned)nblk), dim3(1024), 0, s, g);
+        else
+            hipLaunchKernelGGL((k_gemm_nt<false, false, 1024>), dim3((unsigned)nblk), dim3(1024), 0, s, g);
+    } else {
+        if (g.rhs)
+            hipLaunchKernelGGL((k_gemm_nt<true, true, 512>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+        else if (neg)
+            hipLaunchKernelGGL((k_gemm_nt<true, false, 512>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+        else
+            hipLaunchKernelGGL((k_gemm_nt<false, false, 512>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+    }
     sf_prof_gemm_end(tok);
     SF_LAUNCH_CHECK();
     return SF_OK;
