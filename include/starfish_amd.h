@@ -98,6 +98,12 @@ int sf_chebyshev_correct(const double* d_wave, int n, double wave_max, const dou
                          int rows, const double* h_coeffs, int ncoef, double* d_out,
                          void* stream);
 
+/* Starfish/transforms.py:161-206  extinct(wave, flux, Av, Rv, law="ccm89"): flux * 10^(-0.4 A_lambda),
+ * A_lambda = Av (a(x) + b(x)/Rv) from Cardelli, Clayton & Mathis (1989).  PARITY UNPINNED (the
+ * reference calls the third-party `extinction` package); only the default law is provided. */
+int sf_extinct_ccm89(const double* d_wave, int n, const double* d_flux, int rows, double Av, double Rv,
+                     double* d_out, void* stream);
+
 /* scipy.linalg.cho_factor call site Starfish/models/spectrum_model.py:400 (LAPACK dpotrf).
  * In-place batched lower Cholesky of `batch` matrices, matrix b at d_A + b*stride (doubles),
  * n must be a multiple of 64 (callers pad with an identity block), row stride lda.
@@ -154,6 +160,8 @@ int sf_ctx_lda(const sf_ctx* ctx);  /* row stride used for the covariance matric
  *   [6 .. 6+n_grid)             emulator grid parameters
  *   [.. +n_cheb)                c1, c2, ...   (c0 == 1, spectrum_model.py:301-304)
  *   [.. +3*n_local)             (mu, log_amp, log_sigma) per local kernel
+ *   [.. +1)                     Av, only when has_av (extinct(), Starfish/transforms.py:161-206 as
+ *                               called at spectrum_model.py:298-299: law ccm89, Rv = 3.1)
  * Unused slots are ignored.  Row stride = sf_param_stride(). */
 typedef struct sf_model_desc {
     int32_t has_vsini;
@@ -164,7 +172,10 @@ typedef struct sf_model_desc {
     int32_t n_cheb;
     int32_t use_sigma_w; /* 0 (default, parity): C_emu = X^T Sigma_w^-1 X as the code does
                             (spectrum_model.py:334-335); 1: X^T Sigma_w X as the paper says  */
-    int32_t reserved;
+    int32_t has_av;      /* 1: multiply every row by 10^(-0.4 A_lambda), A_lambda from the published
+                            CCM89 law (Cardelli, Clayton & Mathis 1989) with Rv = 3.1.  PARITY
+                            UNPINNED: the reference delegates this to the third-party `extinction`
+                            C extension, which is not available to generate vectors from.          */
 } sf_model_desc;
 
 int sf_param_stride(const sf_ctx* ctx, const sf_model_desc* model);
@@ -208,6 +219,10 @@ int sf_loglike_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const doubl
  * sf_loglike_batch calls; then it resets the counters. */
 int sf_profile_enable(int on);
 int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches, long* calls);
+
+/* Tuning aid: one wave spins for `wall_ticks_100mhz` ticks of the 100 MHz wall clock on `stream` and
+ * writes {shader-clock ticks, wall ticks} to d_out2[2] -> sustained shader clock under load. */
+int sf_debug_clock_probe(long long* d_out2, long long wall_ticks_100mhz, void* stream);
 
 #ifdef __cplusplus
 }

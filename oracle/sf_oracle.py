@@ -146,6 +146,40 @@ def cheb_correct(wave, flux, coeffs):
     return flux * chebval(wave / wave.max(), coeffs, tensor=False)
 
 
+def ccm89_a_lambda(wave, a_v, r_v=3.1):
+    """A_lambda [mag] of Cardelli, Clayton & Mathis (1989, ApJ 345, 245; eqs. 2a-5b).
+    PARITY UNPINNED: the reference (Starfish/transforms.py:161-206) calls the third-party
+    ``extinction==0.4.*`` package (setup.py:45) which is not in /root/reference and not installed, so no
+    reference output exists to pin this against; it is checked against the paper's Table 3 only."""
+    x = 1e4 / np.asarray(wave, dtype=np.float64)
+    a = np.zeros_like(x)
+    b = np.zeros_like(x)
+    ir = x < 1.1
+    a[ir] = 0.574 * x[ir] ** 1.61
+    b[ir] = -0.527 * x[ir] ** 1.61
+    op = (x >= 1.1) & (x <= 3.3)
+    y = x[op] - 1.82
+    a[op] = 1 + 0.17699 * y - 0.50447 * y**2 - 0.02427 * y**3 + 0.72085 * y**4 + 0.01979 * y**5 \
+        - 0.77530 * y**6 + 0.32999 * y**7
+    b[op] = 1.41338 * y + 2.28305 * y**2 + 1.07233 * y**3 - 5.38434 * y**4 - 0.62251 * y**5 \
+        + 5.30260 * y**6 - 2.09002 * y**7
+    uv = (x > 3.3) & (x <= 8.0)
+    xu = x[uv]
+    d = np.where(xu >= 5.9, xu - 5.9, 0.0)
+    a[uv] = 1.752 - 0.316 * xu - 0.104 / ((xu - 4.67) ** 2 + 0.341) - 0.04473 * d**2 - 0.009779 * d**3
+    b[uv] = -3.090 + 1.825 * xu + 1.206 / ((xu - 4.62) ** 2 + 0.263) + 0.2130 * d**2 + 0.1207 * d**3
+    fuv = x > 8.0
+    d = x[fuv] - 8.0
+    a[fuv] = -1.073 - 0.628 * d + 0.137 * d**2 - 0.070 * d**3
+    b[fuv] = 13.670 + 4.257 * d - 0.420 * d**2 + 0.374 * d**3
+    return a_v * (a + b / r_v)
+
+
+def extinct_ccm89(wave, flux, a_v, r_v=3.1):
+    """flux * 10**(-0.4 A_lambda)  (Starfish/transforms.py:205).  PARITY UNPINNED, see above."""
+    return flux * 10 ** (-0.4 * ccm89_a_lambda(wave, a_v, r_v))
+
+
 def trapezoid(y, x):
     """numpy.trapz as called from Starfish/transforms.py:265-268."""
     y = np.asarray(y, dtype=np.float64)
@@ -354,6 +388,8 @@ def forward_model(order, p):
     if "vz" in p:
         wave = doppler(wave, p["vz"])
     rows = quintic_resample(wave, rows, order.wave)
+    if "Av" in p:  # spectrum_model.py:298-299 (Rv is never passed: 3.1); PARITY UNPINNED
+        rows = extinct_ccm89(order.wave, rows, p["Av"])
     if "cheb" in p:
         rows = cheb_correct(order.wave, rows, [1, *p["cheb"]])
     w_mu, w_cov = emulator_query(

@@ -119,11 +119,13 @@ class DeviceOrder:
             pass
 
     # ------------------------------------------------------------------ helpers
-    def model_desc(self, has_vsini, has_vz, has_log_scale, has_global, n_local, n_cheb, use_sigma_w=False):
+    def model_desc(self, has_vsini, has_vz, has_log_scale, has_global, n_local, n_cheb, use_sigma_w=False,
+                   has_av=False):
         md = _lib.ModelDesc()
         md.has_vsini, md.has_vz = int(has_vsini), int(has_vz)
         md.has_log_scale, md.has_global = int(has_log_scale), int(has_global)
         md.n_local, md.n_cheb, md.use_sigma_w = int(n_local), int(n_cheb), int(use_sigma_w)
+        md.has_av = int(has_av)
         return md
 
     def param_stride(self, md):

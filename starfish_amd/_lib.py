@@ -46,7 +46,7 @@ class ModelDesc(C.Structure):
         ("n_local", C.c_int32),
         ("n_cheb", C.c_int32),
         ("use_sigma_w", C.c_int32),
-        ("reserved", C.c_int32),
+        ("has_av", C.c_int32),
     ]
 
 
@@ -77,6 +77,7 @@ SIGNATURES = {
         C.c_int,
         [_VP, C.c_int, C.c_double, _VP, C.c_int, c_double_p, C.c_int, _VP, _VP],
     ),
+    "sf_extinct_ccm89": (C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_double, C.c_double, _VP, _VP]),
     "sf_potrf_batch": (
         C.c_int,
         [_VP, C.c_int, C.c_int, C.c_int64, C.c_int, _VP, _VP, C.c_size_t, _VP],
@@ -108,6 +109,7 @@ SIGNATURES = {
         C.c_int,
         [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
     ),
+    "sf_debug_clock_probe": (C.c_int, [_VP, C.c_longlong, _VP]),
     "sf_profile_enable": (C.c_int, [C.c_int]),
     "sf_profile_read": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
 }

@@ -425,7 +425,7 @@ static int model_ok(const sf_ctx* c, const sf_model_desc* mdl) {
 }
 extern "C" int sf_param_stride(const sf_ctx* c, const sf_model_desc* mdl) {
     if (model_ok(c, mdl)) return SF_EINVAL;
-    return 6 + c->P + mdl->n_cheb + 3 * mdl->n_local;
+    return 6 + c->P + mdl->n_cheb + 3 * mdl->n_local + (mdl->has_av ? 1 : 0);
 }
 
 // ----------------------------------------------------------------------------------- workspace
@@ -556,6 +556,8 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
     ev.has_vz = mdl->has_vz;
     ev.n_cheb = mdl->n_cheb;
     ev.off_cheb = 6 + c->P;
+    ev.has_av = mdl->has_av;
+    ev.off_av = 6 + c->P + mdl->n_cheb + 3 * mdl->n_local;
     ev.wave_max = c->wave_max;
     rc = sf_launch_eval_rows(ev, B, s);
     if (rc) return rc;
@@ -864,6 +866,15 @@ extern "C" int sf_chebyshev_correct(const double* d_wave, int n, double wave_max
     return rc;
 }
 
+extern "C" int sf_extinct_ccm89(const double* d_wave, int n, const double* d_flux, int rows, double Av, double Rv,
+                                double* d_out, void* stream) {
+    if (!d_wave || !d_flux || !d_out || n < 0 || rows <= 0 || !(Rv > 0.0)) {
+        sf_set_error("sf_extinct_ccm89: bad argument");
+        return SF_EINVAL;
+    }
+    return sf_launch_extinct_rows(d_wave, n, d_flux, rows, Av, Rv, d_out, (hipStream_t)stream);
+}
+
 extern "C" size_t sf_potrf_workspace_bytes(int n, int batch) {
     if (n <= 0 || batch <= 0) return 0;
     // z scratch of the stand-alone solve + the transposed leaf factor read by the panel solves
@@ -892,4 +903,9 @@ extern "C" int sf_logdet_sqmah_batch(const double* d_L, int n, int lda, int64_t 
     ProfScope ps((hipStream_t)stream, PS_SOLVE);
     return sf_launch_logdet_sqmah(d_L, n, lda, stride, batch, d_R, ldr, z, d_logdet, d_sqmah,
                                   (hipStream_t)stream);
+}
+
+// Tuning aid (not part of the Starfish surface): sustained shader clock while other streams are busy.
+extern "C" int sf_debug_clock_probe(long long* d_out2, long long wall_ticks_100mhz, void* stream) {
+    return sf_launch_clock_probe(d_out2, wall_ticks_100mhz, (hipStream_t)stream);
 }

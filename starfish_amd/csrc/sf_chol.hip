@@ -958,3 +958,26 @@ int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int 
     SF_LAUNCH_CHECK();
     return SF_OK;
 }
+
+// Debug aid for the tuning scripts: one wave spins for `wall_ticks` ticks of the 100 MHz wall clock and
+// reports how many shader-clock ticks (s_memtime) elapsed -> sustained shader clock while other
+// streams are busy.  out[0] = s_memtime ticks, out[1] = wall ticks.
+__global__ void k_clock_probe(long long* out, long long wall_ticks) {
+    const long long w0 = wall_clock64();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    long long w1 = w0;
+    while (w1 - w0 < wall_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        w1 = wall_clock64();
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = t1 - t0;
+        out[1] = w1 - w0;
+    }
+}
+int sf_launch_clock_probe(long long* out, long long wall_ticks, hipStream_t s) {
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, out, wall_ticks);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}

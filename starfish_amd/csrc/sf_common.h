@@ -49,6 +49,8 @@ int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batc
 int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int batch,
                            const double* R, int ldr, double* zscratch, double* logdet, double* sqmah, hipStream_t s);
 
+int sf_launch_clock_probe(long long* out, long long wall_ticks, hipStream_t s);
+
 // sf_fill.hip
 struct sf_fill_args {
     const double* wave;    // [n]

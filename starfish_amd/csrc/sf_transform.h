@@ -41,6 +41,7 @@ struct sf_eval_args {
     double* flux;          // [B][ldx]     unscaled reconstruction
     const int* info;
     int n, nf, m, ldx, pstride, has_vz, n_cheb, off_cheb;
+    int has_av, off_av;
     double wave_max;
 };
 int sf_launch_eval_rows(const sf_eval_args& a, int B, hipStream_t s);
@@ -71,6 +72,8 @@ struct sf_resid_args {
 };
 int sf_launch_resid_y(const sf_resid_args& a, int B, hipStream_t s);
 
+int sf_launch_extinct_rows(const double* wave, int n, const double* flux, int rows, double Av, double Rv,
+                           double* out, hipStream_t s);
 int sf_launch_cheb_rows(const double* wave, int n, double wave_max, const double* flux, int rows,
                         const double* d_coeffs, int ncoef, double* out, hipStream_t s);
 

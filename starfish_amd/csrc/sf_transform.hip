@@ -318,6 +318,47 @@ __device__ __forceinline__ double sf_chebval(double x, const double* __restrict_
     return a0 + a1 * x;
 }
 
+// Cardelli, Clayton & Mathis (1989) extinction law A(lambda)/A(V) = a(x) + b(x)/Rv, x = 1/lambda[um]
+// (their eqs. 2a-5b).  Reference call site: extinct() Starfish/transforms.py:161-206 -> third-party
+// `extinction.ccm89`; PARITY UNPINNED (that package is not available), checked against the paper's
+// Table 3 only.  Returns the flux multiplier 10^(-0.4 Av (a + b/Rv)).
+__device__ __forceinline__ double sf_ccm89_mult(double wave_A, double Av, double Rv) {
+    const double x = 1e4 / wave_A;
+    double a, b;
+    if (x < 1.1) {
+        const double p = pow(x, 1.61);
+        a = 0.574 * p;
+        b = -0.527 * p;
+    } else if (x <= 3.3) {
+        const double y = x - 1.82;
+        a = 1 + y * (0.17699 + y * (-0.50447 + y * (-0.02427 + y * (0.72085 + y * (0.01979 + y * (-0.77530 + y * 0.32999))))));
+        b = y * (1.41338 + y * (2.28305 + y * (1.07233 + y * (-5.38434 + y * (-0.62251 + y * (5.30260 + y * -2.09002))))));
+    } else if (x <= 8.0) {
+        double fa = 0.0, fb = 0.0;
+        if (x >= 5.9) {
+            const double d = x - 5.9;
+            fa = -0.04473 * d * d - 0.009779 * d * d * d;
+            fb = 0.2130 * d * d + 0.1207 * d * d * d;
+        }
+        a = 1.752 - 0.316 * x - 0.104 / ((x - 4.67) * (x - 4.67) + 0.341) + fa;
+        b = -3.090 + 1.825 * x + 1.206 / ((x - 4.62) * (x - 4.62) + 0.263) + fb;
+    } else {
+        const double d = x - 8.0;
+        a = -1.073 - 0.628 * d + 0.137 * d * d - 0.070 * d * d * d;
+        b = 13.670 + 4.257 * d - 0.420 * d * d + 0.374 * d * d * d;
+    }
+    return pow(10.0, -0.4 * (Av * (a + b / Rv)));
+}
+
+__global__ __launch_bounds__(256) void k_extinct_rows(const double* __restrict__ wave, int n,
+                                                      const double* __restrict__ flux, int rows, double Av,
+                                                      double Rv, double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double mlt = sf_ccm89_mult(wave[i], Av, Rv);
+    for (int r = 0; r < rows; ++r) out[(int64_t)r * n + i] = flux[(int64_t)r * n + i] * mlt;
+}
+
 // Generic resample (free function): out[r][q] = spline_r(xq[q]); coefficients coef[r][j] row-major.
 __global__ __launch_bounds__(256) void k_spline_eval(const double* __restrict__ coef, int rows, int ncoef,
                                                      const double* __restrict__ t,
@@ -358,10 +399,13 @@ __global__ __launch_bounds__(256) void k_eval_rows(sf_eval_args a) {
         (a.coef_batched ? a.coef + (int64_t)b * a.nf * rows : a.coef) + (int64_t)(ell - 5) * rows;
     double p = 1.0;
     if (a.n_cheb > 0) p = sf_chebval(x / a.wave_max, P + a.off_cheb, a.n_cheb + 1, 1.0);  // transforms.py:302-304
+    double ext = 1.0;
+    if (a.has_av) ext = sf_ccm89_mult(x, P[a.off_av], 3.1);  // spectrum_model.py:298-299 (Rv never passed)
     auto rowval = [&](int r) {
         double sp = 0.0;
 #pragma unroll
         for (int j = 0; j < 6; ++j) sp = sp + cf[(int64_t)j * rows + r] * h[j];
+        if (a.has_av) sp = sp * ext;  // extinct before the Chebyshev correction, as the reference orders them
         return a.n_cheb > 0 ? sp * p : sp;
     };
     const double mean = rowval(a.m), std = rowval(a.m + 1);
@@ -665,6 +709,13 @@ int sf_launch_resid_y(const sf_resid_args& a, int B, hipStream_t s) {
         return SF_EINVAL;
     }
     hipLaunchKernelGGL(k_resid_y, dim3((a.ldy + 255) / 256, B), dim3(256), 0, s, a);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_extinct_rows(const double* wave, int n, const double* flux, int rows, double Av, double Rv,
+                           double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_extinct_rows, dim3((n + 255) / 256), dim3(256), 0, s, wave, n, flux, rows, Av, Rv, out);
     SF_LAUNCH_CHECK();
     return SF_OK;
 }

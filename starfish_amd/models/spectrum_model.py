@@ -301,7 +301,7 @@ class SpectrumModel:
         n_cheb = len(self.params["cheb"]) if "cheb" in self.params else 0
         return dev.model_desc(
             "vsini" in self.params, "vz" in self.params, "log_scale" in self.params,
-            "global_cov" in self.params, n_local, n_cheb,
+            "global_cov" in self.params, n_local, n_cheb, has_av="Av" in self.params,
         )
 
     def _slot_of(self, dev, md):
@@ -317,18 +317,12 @@ class SpectrumModel:
         for i in range(md.n_local):
             for j, leaf in enumerate(self._LOCAL_PARAMS):
                 slots[f"local_cov:{i}:{leaf}"] = off_local + 3 * i + j
+        if md.has_av:
+            slots["Av"] = off_local + 3 * md.n_local  # Rv is accepted but never passed on (as the reference)
         return slots
-
-    def _check_extinction(self):
-        if "Av" in self.params and self.params["Av"] != 0:
-            raise NotImplementedError(
-                "Av != 0 needs the third-party `extinction` laws (parity unpinned, SURVEY.md f-3); "
-                "only Av = 0 is supported"
-            )
 
     def _pack(self, P=None, update_caches=True):
         """Rows for the C-ABI.  ``P`` is None (current state, one row) or (B, len(labels))."""
-        self._check_extinction()
         dev = self._device()
         md = self._model_desc(dev)
         slots = self._slot_of(dev, md)

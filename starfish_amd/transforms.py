@@ -86,16 +86,30 @@ def doppler_shift(wave, vz):
 
 
 def extinct(wave, flux, Av, Rv=3.1, law="ccm89"):
-    """Interstellar extinction (Starfish/transforms.py:161-206).  The reference delegates A_lambda to
-    the third-party ``extinction`` C extension, which is not part of the reference tree: parity is
-    unpinned, so only the identity case Av == 0 is provided."""
+    """Interstellar extinction ``flux * 10**(-0.4 * A_lambda)`` (Starfish/transforms.py:161-206).
+
+    PARITY UNPINNED: the reference obtains ``A_lambda`` from the third-party ``extinction`` C extension,
+    which is not part of the reference tree and cannot be run here to generate vectors.  The default law
+    ``ccm89`` is implemented from the published Cardelli, Clayton & Mathis (1989) formulas and checked
+    against that paper's Table 3; the other laws raise ``NotImplementedError``."""
     if law not in ["ccm89", "odonnell94", "calzetti00", "fitzpatrick99", "fm07"]:
         raise ValueError("Invalid extinction law given")
     if Rv <= 0:
         raise ValueError("Rv must be positive")
-    if Av == 0:
-        return np.asarray(flux, dtype=np.float64) * 1.0
-    raise NotImplementedError("extinct(Av != 0) is not part of the MI355X hot path yet (parity unpinned)")
+    if law != "ccm89":
+        raise NotImplementedError(f"extinction law {law!r} is not provided (only the default 'ccm89')")
+    lib = _lib.require_gpu()
+    wave = np.asarray(wave, dtype=np.float64)
+    rows, one_d = _rows(flux)
+    dev = D.device_of()
+    d_wave = D.to_dev(wave, dev)
+    d_flux = D.to_dev(rows, dev)
+    d_out = D.empty(rows.shape, dev)
+    rc = lib.sf_extinct_ccm89(D.ptr(d_wave), wave.shape[0], D.ptr(d_flux), rows.shape[0], float(Av), float(Rv),
+                              D.ptr(d_out), D.stream_ptr(dev))
+    _lib.check(rc, "sf_extinct_ccm89")
+    out = d_out.cpu().numpy()
+    return out[0] if one_d else out
 
 
 def rescale(flux, scale):

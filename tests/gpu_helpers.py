@@ -24,7 +24,7 @@ def device_order(oo):
 def model_desc(dev_order, p):
     return dev_order.model_desc(
         "vsini" in p, "vz" in p, "log_scale" in p, "global_cov" in p, len(p.get("local_cov", [])),
-        len(p.get("cheb", [])),
+        len(p.get("cheb", [])), has_av="Av" in p,
     )
 
 
@@ -45,6 +45,9 @@ def pack_rows(dev_order, plist):
         r[6 : 6 + P] = p["grid"]
         nc = len(p.get("cheb", []))
         r[6 + P : 6 + P + nc] = p.get("cheb", [])
+        nl = len(p.get("local_cov", []))
         for k, (mu, la, ls) in enumerate(p.get("local_cov", [])):
             r[6 + P + nc + 3 * k : 6 + P + nc + 3 * k + 3] = (mu, la, ls)
+        if "Av" in p:
+            r[6 + P + nc + 3 * nl] = p["Av"]
     return md, rows

@@ -203,3 +203,21 @@ def test_cfg5_long_order_n16384_vs_reference():
     assert abs(out["logdet"][0] - ref[1]) <= 1e-10 * abs(ref[1])
     assert abs(out["sqmah"][0] - ref[2]) <= 1e-8 * abs(ref[2])
     np.testing.assert_allclose(out["resid"][0], g["n16384_flux"] - oo.flux, rtol=0, atol=1e-10)
+
+
+def test_model_with_extinction_matches_oracle_unpinned():
+    """Av in the model (reference test fixture uses Av=0, tests/conftest.py:123): Av = 0 reproduces the
+    reference value exactly; Av != 0 is checked against the (parity-unpinned) oracle restatement."""
+    g = load_golden("model_small.npz")
+    o = synth.make_order(N=256, m=4, seed=5)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    base = small_params(o, "full", g["factors"])
+    p0 = dict(base, Av=0.0)
+    p1 = dict(base, Av=0.35)
+    md, rows = pack_rows(do, [p0, p1])
+    out = do.loglike(md, rows)
+    assert (out["info"] == 0).all()
+    assert close_lnl(out["lnl"][0], g["full_lnl"][0])
+    assert close_lnl(out["lnl"][1], O.log_likelihood(oo, p1))
+    assert out["lnl"][0] != out["lnl"][1]

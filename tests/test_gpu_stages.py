@@ -159,3 +159,22 @@ def test_emulator_query_vs_reference(gpu, tag, m):
         np.testing.assert_allclose(cov[i], g[f"{tag}_cov_{i}"], rtol=1e-9, atol=1e-9)
     _, _, info = do.emulator_query([[5999.0, 4.2, -0.3], [6050.0, 4.2, 0.01]])
     assert info.tolist() == [-1, -1]
+
+
+def test_extinct_ccm89_unpinned_law(gpu):
+    """extinct(): Av = 0 identity is the only case the reference's tests pin (tests/test_transforms.py:
+    162-165); the CCM89 law itself is parity-unpinned and checked against the restated formulas."""
+    from oracle import sf_oracle as O
+    from starfish_amd import transforms as T
+
+    w = np.linspace(1200.0, 30000.0, 777)  # far-UV .. near-IR: every branch of the law
+    f = 1.0 + 0.1 * np.random.default_rng(0).standard_normal((3, 777))
+    np.testing.assert_array_equal(T.extinct(w, f, 0.0), f)
+    np.testing.assert_allclose(T.extinct(w, f, 0.7), O.extinct_ccm89(w, f, 0.7), rtol=1e-13)
+    np.testing.assert_allclose(T.extinct(w, f[0], 1.3, Rv=4.0), O.extinct_ccm89(w, f[0], 1.3, 4.0), rtol=1e-13)
+    with pytest.raises(ValueError):
+        T.extinct(w, f, 1.0, law="nope")
+    with pytest.raises(ValueError):
+        T.extinct(w, f, 1.0, Rv=-1.0)
+    with pytest.raises(NotImplementedError):
+        T.extinct(w, f, 1.0, law="fm07")

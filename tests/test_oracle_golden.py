@@ -130,3 +130,22 @@ def test_large_model_known_answers():
         got = O.log_likelihood(oo, synth.vector_to_oracle_params(p))
         assert abs(got - want) <= 1e-10 * abs(want)
     np.testing.assert_allclose(P, synth.walker_ball(o, B=128)[: len(P)], rtol=0, atol=0)
+
+
+def test_ccm89_against_the_papers_table3():
+    """extinct() parity is UNPINNED (third-party `extinction` absent): the restated CCM89 law is held to
+    Cardelli, Clayton & Mathis (1989) Table 3 (Rv = 3.1) and to its defining identities."""
+    band_x = np.array([2.78, 1.82, 1.43, 1.11, 0.80])  # U V R I J  [1/um]
+    table = np.array([1.569, 1.000, 0.751, 0.479, 0.282])
+    got = O.ccm89_a_lambda(1e4 / band_x, 1.0, 3.1)
+    np.testing.assert_allclose(got, table, atol=1.5e-3)
+    # A_B - A_V = E(B-V) = A_V / Rv at the nominal B wavelength used by CCM89 (x = 2.27)
+    assert abs(O.ccm89_a_lambda([1e4 / 2.27], 1.0, 3.1)[0] - (1 + 1 / 3.1)) < 2e-3
+    # continuity at the segment joins and linearity in Av
+    for xj in (1.1, 3.3, 8.0):
+        lo, hi = O.ccm89_a_lambda([1e4 / (xj - 1e-9), 1e4 / (xj + 1e-9)], 1.0)
+        assert abs(lo - hi) < 5e-3
+    w = np.linspace(3000, 25000, 50)
+    np.testing.assert_allclose(O.ccm89_a_lambda(w, 2.5), 2.5 * O.ccm89_a_lambda(w, 1.0), rtol=1e-14)
+    f = np.ones((2, 50))
+    np.testing.assert_array_equal(O.extinct_ccm89(w, f, 0.0), f)  # reference test: Av = 0 is the identity

@@ -44,6 +44,20 @@ for it in range(reps + 1):
     if it:
         print(f"N={N} B={B}: potrf {dt*1e3:.2f} ms = {B*N**3/3/dt/1e12:.1f} TF whole;  mfma kernels {ms[2]:.2f} ms "
               f"({fl.value/ms[2]/1e9:.1f} TF algorithmic over {nl.value} launches)")
+# sustained shader clock while the factorisation runs (probe wave on its own stream)
+probe = torch.zeros(2, dtype=torch.int64, device=dev)
+side = torch.cuda.Stream(device=dev)
+A.copy_(base.unsqueeze(0).expand(B, N, lda))
+torch.cuda.synchronize()
+lib.sf_debug_clock_probe(D.ptr(probe), 4_000_000, C.c_void_p(side.cuda_stream))  # 40 ms window
+_lib.check(lib.sf_potrf_batch(D.ptr(A), N, lda, N * lda, B, D.ptr(info), D.ptr(ws), ws.numel(), s))
+torch.cuda.synchronize()
+t, w = probe.cpu().tolist()
+print(f"shader clock during potrf: {100.0 * t / w:.0f} MHz  (fp64 MFMA peak at that clock: {78.6 * (t / w) / 24.0:.1f} TFLOP/s)")
+lib.sf_debug_clock_probe(D.ptr(probe), 1_000_000, C.c_void_p(side.cuda_stream))
+torch.cuda.synchronize()
+t, w = probe.cpu().tolist()
+print(f"shader clock idle: {100.0 * t / w:.0f} MHz")
 assert int(info.abs().max()) == 0
 L = torch.tril(A[0, :, :N])
 err = (L @ L.T - base[:, :N]).abs().max().item()
