@@ -214,9 +214,10 @@ int sf_loglike_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const doubl
 /* Timing hooks for bench.py (process-global, not thread-safe): when enabled, the batched calls
  * record HIP events on the caller's stream around each stage and around every MFMA update launch.
  * sf_profile_read synchronises those events, returns the milliseconds accumulated since the last
- * read in ms_by_stage[5] = {transforms, fill, mfma update kernel (k_gemm_nt), whole potrf, solve},
- * the algorithmic flops and launch count of the MFMA update kernel, and the number of
- * sf_loglike_batch calls; then it resets the counters. */
+ * read in ms_by_stage[6] = {transforms, fill, k_gemm_nt launches (overlapping launches of the two
+ * Cholesky streams merged: union of their intervals), whole potrf, solve, k_gemm_nt launches (plain
+ * sum of launch durations)}, the algorithmic flops and launch count of k_gemm_nt, and the number
+ * of sf_loglike_batch calls; then it resets the counters. */
 int sf_profile_enable(int on);
 int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches, long* calls);
 

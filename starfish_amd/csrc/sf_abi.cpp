@@ -2,10 +2,12 @@
 // sequences.  Host code only prepares constants that the reference recomputes on every call but that
 // do not depend on the walker (collocation factor of the fixed log-lambda grid, factor of the
 // constant v11); all per-walker arithmetic runs in the HIP kernels.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "sf_common.h"
@@ -41,6 +43,7 @@ static struct {
     double gemm_flops = 0.0;
     long gemm_launches = 0;
     long calls = 0;
+    hipEvent_t ref = nullptr;  // common time origin for merging overlapping launch intervals
 } g_prof;
 
 static hipEvent_t prof_event() {
@@ -85,21 +88,48 @@ void sf_prof_gemm_end(void* tok) {
 
 extern "C" int sf_profile_enable(int on) {
     g_prof.on = on;
+    if (on) {
+        if (!g_prof.ref) SF_HIP(hipEventCreate(&g_prof.ref));
+        SF_HIP(hipEventRecord(g_prof.ref, 0));
+    }
     return SF_OK;
 }
 extern "C" int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches, long* calls) {
-    double acc[PS_COUNT] = {0, 0, 0, 0, 0};
+    double acc[PS_COUNT + 1] = {0, 0, 0, 0, 0, 0};
+    std::vector<std::pair<double, double>> gemm_iv;  // [start, end) of every MFMA launch, ms since ref
     for (auto& sp : g_prof.spans) {
         float ms = 0.f;
         SF_HIP(hipEventSynchronize(sp.b));
         SF_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
         acc[sp.stage] += ms;
+        if (sp.stage == PS_GEMM && g_prof.ref) {
+            float ta = 0.f;
+            if (hipEventElapsedTime(&ta, g_prof.ref, sp.a) == hipSuccess) gemm_iv.emplace_back(ta, ta + ms);
+        }
         g_prof.pool.push_back(sp.a);
         g_prof.pool.push_back(sp.b);
     }
     g_prof.spans.clear();
+    // launches on the two streams of the Cholesky overlap: merge the intervals so that concurrent
+    // launches are not counted twice (slot 2 = union, slot 5 = plain sum of launch durations)
+    acc[PS_COUNT] = acc[PS_GEMM];
+    if (!gemm_iv.empty()) {
+        std::sort(gemm_iv.begin(), gemm_iv.end());
+        double uni = 0.0, lo = gemm_iv[0].first, hi = gemm_iv[0].second;
+        for (size_t i = 1; i < gemm_iv.size(); ++i) {
+            if (gemm_iv[i].first <= hi) {
+                if (gemm_iv[i].second > hi) hi = gemm_iv[i].second;
+            } else {
+                uni += hi - lo;
+                lo = gemm_iv[i].first;
+                hi = gemm_iv[i].second;
+            }
+        }
+        uni += hi - lo;
+        acc[PS_GEMM] = uni;
+    }
     if (ms_by_stage)
-        for (int i = 0; i < PS_COUNT; ++i) ms_by_stage[i] = acc[i];
+        for (int i = 0; i < PS_COUNT + 1; ++i) ms_by_stage[i] = acc[i];
     if (gemm_flops) *gemm_flops = g_prof.gemm_flops;
     if (gemm_launches) *gemm_launches = g_prof.gemm_launches;
     if (calls) *calls = g_prof.calls;

@@ -28,7 +28,7 @@ A = torch.empty((B, N, lda), dtype=torch.float64, device=dev)
 info = torch.empty((B,), dtype=torch.int32, device=dev)
 ws = D.workspace(lib.sf_potrf_workspace_bytes(N, B), dev)
 s = D.stream_ptr(dev)
-ms = (C.c_double * 5)()
+ms = (C.c_double * 6)()
 fl, nl, nc = C.c_double(), C.c_long(), C.c_long()
 for it in range(reps + 1):
     A.copy_(base.unsqueeze(0).expand(B, N, lda))

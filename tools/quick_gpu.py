@@ -22,6 +22,6 @@ print(lnl[:4].cpu().numpy(), info[:4].cpu().numpy())
 import ctypes as C
 do.lib.sf_profile_enable(1)
 do.loglike_device(md, Pd, lnl, info); torch.cuda.synchronize()
-ms = (C.c_double*5)(); fl=C.c_double(); nl=C.c_long(); nc=C.c_long()
+ms = (C.c_double*6)(); fl=C.c_double(); nl=C.c_long(); nc=C.c_long()
 do.lib.sf_profile_read(ms, C.byref(fl), C.byref(nl), C.byref(nc))
 print("stage ms [transform, fill, gemm, potrf, solve]:", list(ms), "gemm TF:", fl.value/ (ms[2]*1e-3)/1e12, nl.value)

@@ -24,6 +24,24 @@ with open(dst + "_kernel_stats.csv", "w") as fh:
         fh.write(f"{short(r['Name'])},{r['Calls']},{int(r['TotalDurationNs'])/1e6:.3f},"
                  f"{float(r['AverageNs'])/1e3:.2f},{float(r['Percentage']):.2f}\n")
 
+# union of the (overlapping, two-stream) k_gemm_nt launch intervals per bench step, from the kernel trace
+trace_f = os.path.join(src, "stats", "bench_kernel_trace.csv")
+gemm_union = None
+if os.path.exists(trace_f):
+    tr = sorted(csv.DictReader(open(trace_f)), key=lambda r: int(r["Start_Timestamp"]))
+    nsteps = sum(1 for r in tr if r["Kernel_Name"].startswith("k_logdet_z"))
+    iv = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in tr if "k_gemm_nt" in r["Kernel_Name"]]
+    uni, lo, hi = 0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a <= hi:
+            hi = max(hi, b)
+        else:
+            uni += hi - lo
+            lo, hi = a, b
+    uni += hi - lo
+    gemm_union = {"steps": nsteps, "launches": len(iv), "union_ms_per_step": uni / 1e6 / max(1, nsteps),
+                  "sum_ms_per_step": sum(b - a for a, b in iv) / 1e6 / max(1, nsteps)}
+
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(int)
 dur = collections.defaultdict(float)
@@ -69,6 +87,8 @@ summary["_k_gemm_nt_all"] = {
     "hbm_GB_per_step": round(tot_fetch + tot_write, 3),
     "hbm_bytes_per_launch": (tot_fetch + tot_write) * 1e9 / max(1, tot_launch),
 }
+if gemm_union:
+    summary["_k_gemm_nt_all"]["kernel_trace"] = gemm_union
 json.dump(summary, open(dst + "_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(summary["_k_gemm_nt_all"]))
 for k in sorted(summary):
