@@ -49,9 +49,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    if os.environ.get("SF_BENCH_NO_DIST"):
+        use_dist = False
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world
 
     from gpu_helpers import device_order, oracle_order, pack_rows
     from starfish_amd import _device as D
@@ -69,7 +73,7 @@ def main():
     info = D.empty((B,), do.dev, torch.int32)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -83,7 +87,10 @@ def main():
     # steps run (sustained clock under this load; the datasheet peak assumes 2.4 GHz)
     clk = torch.zeros(2, dtype=torch.int64, device=do.dev)
     clk_stream = torch.cuda.Stream(device=do.dev)
-    do.lib.sf_debug_clock_probe(D.ptr(clk), 4_000_000, C.c_void_p(clk_stream.cuda_stream))
+    # (skipped under torch.distributed: with RCCL initialised the spinning probe kernel serialises with the
+    # main stream -- measured +40 ms on the timed region)
+    if not use_dist and not os.environ.get("SF_BENCH_NO_CLOCK"):
+        do.lib.sf_debug_clock_probe(D.ptr(clk), 4_000_000, C.c_void_p(clk_stream.cuda_stream))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         do.loglike_device(md, P_dev, lnl, info)
@@ -93,8 +100,8 @@ def main():
     do.lib.sf_profile_enable(0)
 
     t = torch.tensor([dt], dtype=torch.float64, device=do.dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only: the data path has no collective
     dt_max = float(t.item())
 
     ms = (C.c_double * 6)()
@@ -118,7 +125,7 @@ def main():
                     traffic = json.load(fh)["_k_gemm_nt_all"]["hbm_bytes_per_launch"]
                 traffic_src = os.path.relpath(f, ROOT)
         ticks, wall = clk.cpu().tolist()
-        clock_mhz = 100.0 * ticks / wall if wall else None
+        clock_mhz = 100.0 * ticks / wall if wall else 0.0
         gemm_s = ms[2] * 1e-3
         achieved = gflops.value / gemm_s / 1e12 if gemm_s > 0 else 0.0
         flops_eval = N**3 / 3 + 2 * 8 * N**2 + N**2
@@ -149,7 +156,7 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "sustained_clock_mhz": clock_mhz,
+                "sustained_clock_mhz": clock_mhz or None,
                 "peak_at_sustained_clock": FP64_MFMA_PEAK_TFLOPS * clock_mhz / 2400.0 if clock_mhz else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
@@ -193,7 +200,7 @@ def main():
             }
             assert rel.max() < 1e-8, rel
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
