@@ -5,7 +5,8 @@ Kept: the constructor and its attributes, ``__call__`` (GP conditional mean / co
 weights), ``bulk_fluxes``, ``norm_factor``, hyper-parameter accessors, ``load`` / ``save``.
 ``__call__`` runs in the ``k_emulator`` HIP kernel through ``sf_emulator_query_batch``; the constant
 ``v11`` is factored once per hyper-parameter set instead of on every call (emulator.py:387-388).
-Out of scope (one-time offline set-up): ``from_grid``, ``train``, plotting.
+``log_likelihood`` / ``train`` reuse the batched Cholesky kernels.
+Out of scope (one-time offline set-up): ``from_grid`` (PCA), plotting.
 """
 import logging
 import os
@@ -249,8 +250,64 @@ class Emulator:
     def from_grid(cls, grid, **pca_kwargs):
         raise NotImplementedError("Emulator.from_grid (PCA of a spectral library) is offline set-up, out of scope")
 
+    def log_likelihood(self):
+        """-(logdet v11 + w_hat^T v11^-1 w_hat) / 2  (Starfish/emulator/emulator.py:602-619), with the
+        Cholesky factorisation and the solve done by the same batched HIP kernels as the spectrum
+        likelihood (``sf_potrf_batch`` / ``sf_logdet_sqmah_batch``)."""
+        import ctypes as C
+
+        from .. import _lib
+
+        lib = _lib.require_gpu()
+        torch = D._torch()
+        dev = D.device_of()
+        n = self.v11.shape[0]
+        npad = -(-n // 64) * 64
+        lda = npad + 16
+        A = np.zeros((1, npad, lda))
+        A[0, :n, :n] = self.v11
+        idx = np.arange(n, npad)
+        A[0, idx, idx] = 1.0  # identity padding: log 1 = 0, zero right-hand side
+        R = np.zeros((1, npad))
+        R[0, :n] = self.w_hat
+        dA, dR = D.to_dev(A, dev), D.to_dev(R, dev)
+        info = D.empty((1,), dev, torch.int32)
+        ld, sq = D.empty((1,), dev), D.empty((1,), dev)
+        ws = D.workspace(lib.sf_potrf_workspace_bytes(npad, 1), dev)
+        s = D.stream_ptr(dev)
+        _lib.check(lib.sf_potrf_batch(D.ptr(dA), npad, lda, npad * lda, 1, D.ptr(info), D.ptr(ws), ws.numel(), s),
+                   "sf_potrf_batch")
+        _lib.check(lib.sf_logdet_sqmah_batch(D.ptr(dA), npad, lda, npad * lda, 1, D.ptr(dR), npad, D.ptr(ws),
+                                             ws.numel(), D.ptr(ld), D.ptr(sq), s), "sf_logdet_sqmah_batch")
+        code = int(info.cpu()[0])
+        if code != 0:
+            raise np.linalg.LinAlgError(f"{code}-th leading minor of the array is not positive definite")
+        return -(float(ld.cpu()[0]) + float(sq.cpu()[0])) / 2
+
     def train(self, **opt_kwargs):
-        raise NotImplementedError("Emulator.train is offline set-up, out of scope for the MI355X hot path")
+        """Nelder-Mead over the hyper-parameter vector (Starfish/emulator/emulator.py:484-524); every
+        likelihood evaluation factors v11 on the GPU."""
+        from scipy.optimize import minimize
+
+        def nll(P):
+            if np.any(~np.isfinite(P)):
+                return np.inf
+            self.set_param_vector(P)
+            if np.any(self.lengthscales < 2 * self._grid_sep):
+                return np.inf
+            return -self.log_likelihood()
+
+        kwargs = {"method": "Nelder-Mead", "options": {"maxiter": 10000}}
+        kwargs.update(opt_kwargs)
+        soln = minimize(nll, self.get_param_vector(), **kwargs)
+        if not soln.success:
+            self.log.warning("Optimization did not succeed.")
+            self.log.info(soln.message)
+        else:
+            self.set_param_vector(soln.x)
+            self._trained = True
+            self.log.info("Finished optimizing emulator hyperparameters")
+        return soln
 
     def __repr__(self):
         out = "Emulator\n" + "-" * 8 + "\n"

@@ -161,3 +161,32 @@ def test_echelle_model_sums_orders():
     P[:, em.labels.index("vz")] += [0.0, 0.1, -0.1, 0.2]
     batch = em.log_likelihood_batch(P)
     assert close(batch[0], total) and batch.shape == (4,)
+
+
+@pytest.mark.parametrize("tag,m", [("a", 8), ("b", 4)])
+def test_emulator_training_likelihood_vs_reference(tag, m):
+    """SURVEY f-4: Emulator.log_likelihood on the same Cholesky kernels, against the reference's values."""
+    g = load_golden("emulator.npz")
+    o = synth.make_order(N=256, m=m, seed=3)
+    emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"],
+                   o["w_hat"], o["flux_mean"], o["flux_std"], o["factors"],
+                   variances=g[f"{tag}_variances"], lengthscales=g[f"{tag}_lengthscales"])
+    assert list(g[f"{tag}_train_labels"]) == list(emu.get_param_dict().keys())
+    np.testing.assert_allclose(emu.get_param_vector(), g[f"{tag}_train_P0"], rtol=1e-14)
+    want = g[f"{tag}_loglike"][0]
+    assert abs(emu.log_likelihood() - want) <= 1e-9 * abs(want)
+    emu.set_param_vector(g[f"{tag}_train_P0"] + 0.05)
+    want = g[f"{tag}_loglike_shifted"][0]
+    assert abs(emu.log_likelihood() - want) <= 1e-9 * abs(want)
+    with pytest.raises(ValueError):
+        emu.set_param_vector(g[f"{tag}_train_P0"][:-1])
+
+
+def test_emulator_train_improves_likelihood():
+    """Mirrors the reference's tests/test_emulator/test_emulator.py:87-98 on a short optimisation."""
+    o = synth.make_order(N=256, m=2, seed=3)
+    emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"],
+                   o["w_hat"], o["flux_mean"], o["flux_std"], o["factors"])
+    before = emu.log_likelihood()
+    emu.train(options=dict(maxiter=40))
+    assert emu.log_likelihood() >= before

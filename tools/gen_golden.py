@@ -178,6 +178,14 @@ def gen_emulator():
         out[f"{tag}_lengthscales"] = emu.lengthscales
         out[f"{tag}_v11"] = emu.v11
         out[f"{tag}_bulk"] = emu.bulk_fluxes
+        out[f"{tag}_loglike"] = np.array([emu.log_likelihood()])  # emulator.py:602-619
+        # the same after a hyper-parameter update through the trainable-vector interface
+        emu2, _ = ref_objects(o, variances=var, lengthscales=ls)
+        P = emu2.get_param_vector()
+        out[f"{tag}_train_P0"] = P
+        out[f"{tag}_train_labels"] = np.array(list(emu2.get_param_dict().keys()))
+        emu2.set_param_vector(P + 0.05)
+        out[f"{tag}_loglike_shifted"] = np.array([emu2.log_likelihood()])
         queries = np.array(
             [
                 [6050.0, 4.2, -0.3],
