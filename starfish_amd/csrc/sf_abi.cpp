@@ -475,6 +475,7 @@ struct Work {
     double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf;
     double2* fft;
     int *info_e, *info_c;
+    unsigned char* tilemap;
     size_t bytes;
 };
 static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, size_t cap, bool need_C) {
@@ -498,6 +499,7 @@ static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, siz
     w.Y = k.take<double>(b * c->mpad * c->npad);
     w.ztrsv = k.take<double>(b * c->npad);
     w.ltbuf = need_C ? k.take<double>(sf_potrf_work_doubles(c->npad, B)) : nullptr;  // Cholesky scratch
+    w.tilemap = need_C ? k.take<unsigned char>(b * (size_t)(c->npad / 128 + 1) * (c->npad / 128 + 1)) : nullptr;
     w.C = need_C ? k.take<double>(b * (size_t)c->npad * c->lda) : nullptr;
     w.bytes = sf_align_up(k.off, 256);
     return w;
@@ -647,6 +649,8 @@ static sf_fill_args fill_args(sf_ctx* c, const sf_model_desc* mdl, const double*
     f.off_global = 4;
     f.off_local = 6 + c->P + mdl->n_cheb;
     f.monotonic = c->monotonic;
+    f.tilemap = nullptr;
+    f.nt128 = 0;
     return f;
 }
 
@@ -742,13 +746,21 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
         f.stride = stride;
         f.lower_only = 1;
         f.add_jitter = 1;
+        f.tilemap = w.tilemap;  // only tiles that carry more than the rank-m term are materialised
+        f.nt128 = (c->npad + 127) / 128;
         rc = sf_launch_fill(f, B, s);
         if (rc) return rc;
     }
     {
         ProfScope ps(s, PS_POTRF);
         // the residual rides through the factorisation: w.resid is overwritten with z = L^-1 R
-        rc = sf_launch_potrf(w.C, c->npad, c->lda, stride, B, w.info_c, w.ltbuf, w.resid, c->npad, s);
+        sf_gen_args gen;
+        gen.Y = w.Y;
+        gen.mpad = c->mpad;
+        gen.ldy = c->npad;
+        gen.tilemap = w.tilemap;
+        gen.nt128 = (c->npad + 127) / 128;
+        rc = sf_launch_potrf(w.C, c->npad, c->lda, stride, B, w.info_c, w.ltbuf, w.resid, c->npad, s, &gen);
         if (rc) return rc;
     }
     {

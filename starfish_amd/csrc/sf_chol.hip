@@ -57,6 +57,12 @@ struct sf_gemm_args {
     // diagonal blocks; block j takes A/B at +j*dA and C at +j*dC (M = Nc = total rows covered)
     int diag_blocks;
     int64_t dA, dC;
+    // matrix-free start: if tilemap says this 128 x 128 tile was never materialised, its initial value is
+    // Y^T Y (rank-mpad product of the rows/columns of Y) instead of Cin
+    const double* genY;
+    const unsigned char* tilemap;
+    int64_t sY;
+    int ldy, mpad, nt128, tm_off, tn_off;
     int mt, nt;
 };
 
@@ -112,22 +118,50 @@ __global__ __launch_bounds__(NTH, (NTH == 256) ? 2 : NTH / 128) void k_gemm_nt(s
     const int wm = w / WN, wn = w % WN;  // rows wm*32.., cols wn*(16*TN)..
     const int l15 = lane & 15, lq = lane >> 4;
 
-    // ---- accumulators start as the C tile
+    // ---- accumulators start as the C tile (read, or generated from Y when it was never materialised)
     sf_d4 acc[TM][TN];
     const double* Cin = g.Cin ? g.Cin + (int64_t)b * g.sCin + (int64_t)row0 * g.ldcin + col0 : nullptr;
+    bool generate = false;
+    if (g.tilemap && !g.diag_blocks)
+        generate = !g.tilemap[(int64_t)b * g.nt128 * g.nt128 + (g.tm_off + tm) * g.nt128 + (g.tn_off + tn)];
+    if (generate) {
+        const double* Yb = g.genY + (int64_t)b * g.sY;
+        // global pixel index of this lane's row / column (clamped: Y has ldy columns; rows past the
+        // matrix edge are never stored)
+        const int gr = (g.tm_off + tm) * GT + wm * (16 * TM) + l15;
+        const int gc = (g.tn_off + tn) * GT + wn * (16 * TN) + l15;
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int col = wn * (16 * TN) + ni * 16 + l15;
+            for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < g.mpad; kk += 4) {
+            const double* yk = Yb + (int64_t)(kk + lq) * g.ldy;
+            double ya[TM], yb[TN];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * (16 * TM) + mi * 16 + lq + 4 * r;
-                double v = 0.0;
-                if (Cin && row < rows_here && col < cols_here) v = Cin[(int64_t)row * g.ldcin + col];
-                acc[mi][ni][r] = v;
-            }
+            for (int i = 0; i < TM; ++i) ya[i] = yk[min(gr + i * 16, g.ldy - 1)];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) yb[i] = yk[min(gc + i * 16, g.ldy - 1)];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[mi], yb[ni], acc[mi][ni], 0, 0, 0);
         }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = wn * (16 * TN) + ni * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * (16 * TM) + mi * 16 + lq + 4 * r;
+                    double v = 0.0;
+                    if (Cin && row < rows_here && col < cols_here) v = Cin[(int64_t)row * g.ldcin + col];
+                    acc[mi][ni][r] = v;
+                }
+            }
+    }
 
     // ---- global -> register -> LDS staging: thread covers rows lr+64p, two doubles at column lc.
     // Rows past the block edge are CLAMPED to the last valid row instead of being predicated: the
@@ -763,7 +797,7 @@ static int next_event(hipEvent_t* e) {
 //   side:  D(k) F(k) | wait Ur(k) | Gt(k) Rnext(k -> k+1) | D(k+1) ...
 //   main:  wait Gt(k-1) | Ur(k) | wait F(k) | Gr(k) Rrest(k) | ...
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
-                    double* rhs, int ldr, hipStream_t s) {
+                    double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen) {
     if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
         sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
         return SF_EINVAL;
@@ -845,6 +879,16 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
             g.Nc = pw;
             g.K = k0;
             g.remap_after = 0x7fffffff;
+            if (gen) {
+                g.genY = gen->Y;
+                g.sY = (int64_t)gen->mpad * gen->ldy;
+                g.ldy = gen->ldy;
+                g.mpad = gen->mpad;
+                g.tilemap = gen->tilemap;
+                g.nt128 = gen->nt128;
+                g.tm_off = k1 / GT;
+                g.tn_off = k0 / GT;
+            }
             SF_TRY(launch_gemm(g, batch, true, 2.0 * k0 * (double)nbelow * pw * batch, s));
             SF_TRY(next_event(&e_ur));
             SF_HIP(hipEventRecord(e_ur, s));

@@ -42,8 +42,16 @@ void sf_prof_gemm_end(void* tok);
 #define SF_LTB_DOUBLES (SF_LEAF * SF_LEAF + SF_LEAF)  // side buffer per matrix: L^T of the leaf + its z
 #define SF_LDT (SF_NB + 16)                            // row stride of the panel scratch
 size_t sf_potrf_work_doubles(int n, int batch);        // doubles of scratch sf_launch_potrf needs
+// Optional "matrix-free" start of the factorisation: 128x128 tiles whose tilemap byte is 0 were never
+// written to A; their initial value is the rank-m product Y^T Y and is generated in the MFMA kernel.
+struct sf_gen_args {
+    const double* Y;  // [batch][mpad][ldy]
+    int mpad, ldy;
+    const unsigned char* tilemap;  // [batch][nt128 * nt128]
+    int nt128;
+};
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
-                    double* rhs, int ldr, hipStream_t s);
+                    double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen = nullptr);
 int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batch, const double* z, int ldr,
                        double* logdet, double* sqmah, hipStream_t s);
 int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int batch,
@@ -64,6 +72,8 @@ struct sf_fill_args {
     int lower_only;        // 1: only tiles touching the lower triangle, identity padding written
     int add_jitter;        // 1: + SF_JITTER on the diagonal
     int monotonic;         // wave sorted ascending -> band culling allowed
+    unsigned char* tilemap; // optional [B][nt128*nt128]: 1 = the 128x128 tile is materialised in C
+    int nt128;
 };
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);
 int sf_launch_global_cov(const double* wave, int n, double amp, double ls, double* out, hipStream_t s);

@@ -46,6 +46,46 @@ __device__ __forceinline__ double sf_local_metric(double w, double mu) {
 
 #define SF_MAX_LOCAL 32
 
+// Which 128 x 128 tiles of the lower triangle carry anything besides the rank-m term (diagonal
+// SF_NB blocks: sigma^2 / jitter / identity padding; Matern band; local patches)?  Only those are
+// materialised for the factorisation; the MFMA update kernel generates the others from Y on the fly.
+__global__ __launch_bounds__(256) void k_tile_map(sf_fill_args a) {
+    const int nt = a.nt128;
+    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (e >= nt * nt) return;
+    const int tm = e / nt, tn = e - tm * nt;
+    unsigned char flag = 0;
+    if (tn <= tm) {
+        const int rlo = tm * 128, clo = tn * 128;
+        if (rlo / SF_NB == clo / SF_NB || rlo >= a.n) {
+            flag = 1;  // diagonal block (or pure padding rows)
+        } else {
+            const int rhi = min(rlo + 127, a.n - 1), chi = min(clo + 127, a.n - 1);
+            const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
+            if (a.has_global) {
+                if (!a.monotonic) flag = 1;
+                else {
+                    const double wr = a.wave[rlo], wc = a.wave[chi];  // closest pair: rows are below cols
+                    const double rmin = SF_C_KMS / 2 * fabs((wc - wr) / (wc + wr));
+                    if (rmin <= 6 * exp(P[a.off_global + 1]) * (1 + 1e-9)) flag = 1;
+                }
+            }
+            for (int k = 0; k < a.n_local && !flag; ++k) {
+                if (!a.monotonic) { flag = 1; break; }
+                const double mu = P[a.off_local + 3 * k];
+                const double r0 = 4 * exp(P[a.off_local + 3 * k + 2]);
+                auto dmin = [&](int lo, int hi) {
+                    const double wl = a.wave[lo], wh = a.wave[hi];
+                    if (wl <= mu && mu <= wh) return 0.0;
+                    return fmin(sf_local_metric(wl, mu), sf_local_metric(wh, mu));
+                };
+                if (dmin(rlo, rhi) <= r0 * (1 + 1e-9) && dmin(clo, chi) <= r0 * (1 + 1e-9)) flag = 1;
+            }
+        }
+    }
+    a.tilemap[(int64_t)b * nt * nt + e] = flag;
+}
+
 // Pass 1 (every stored tile): rank-m term on MFMA + sigma^2 on the diagonal + identity padding.
 // Lean on registers so that many waves hide the store latency (the pass is HBM-write bound).
 __global__ __launch_bounds__(256, 4) void k_fill_plain(sf_fill_args a, int nt, int jitter_here) {
@@ -55,6 +95,7 @@ __global__ __launch_bounds__(256, 4) void k_fill_plain(sf_fill_args a, int nt, i
     const int t = id - b * tiles;
     const int tm = t / nt, tn = t - tm * nt;
     if (a.lower_only && tn > tm) return;
+    if (a.tilemap && !a.tilemap[(int64_t)b * a.nt128 * a.nt128 + (tm >> 1) * a.nt128 + (tn >> 1)]) return;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
@@ -136,6 +177,7 @@ __global__ __launch_bounds__(256) void k_fill_band(sf_fill_args a, int nt) {
     const int t = id - b * tiles;
     const int tm = t / nt, tn = t - tm * nt;
     if (a.lower_only && tn > tm) return;
+    if (a.tilemap && !a.tilemap[(int64_t)b * a.nt128 * a.nt128 + (tm >> 1) * a.nt128 + (tn >> 1)]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
     if (R0 >= a.n || C0 >= a.n) return;
@@ -240,6 +282,10 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
     if (nblk > 0x7fffffffLL) {
         sf_set_error("fill grid too large");
         return SF_EINVAL;
+    }
+    if (a.tilemap) {
+        hipLaunchKernelGGL(k_tile_map, dim3((a.nt128 * a.nt128 + 255) / 256, B), dim3(256), 0, s, a);
+        SF_LAUNCH_CHECK();
     }
     const int structured = a.has_global || a.n_local > 0;
     hipLaunchKernelGGL(k_fill_plain, dim3((unsigned)nblk), dim3(256), 0, s, a, nt, structured ? 0 : 1);
