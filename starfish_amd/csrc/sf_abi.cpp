@@ -224,6 +224,34 @@ static int quintic_collocation_lu(const double* x, int n, std::vector<double>& t
     return SF_OK;
 }
 
+// Truncated inverse of the collocation matrix from its band LU, by windowed column solves: column j of
+// A^-1 is obtained with a forward sweep over [j, j+WF] and a backward sweep over [j-WF, j+WF] (entries
+// further out are < 1e-30 of the peak).  band[(j - i + SF_IW) * n + i] = Ainv[i][j] for |i - j| <= SF_IW.
+static void truncated_inverse_band(int n, const std::vector<double>& Lf, const std::vector<double>& Uf,
+                                   const std::vector<double>& rdiag, std::vector<double>& band) {
+    const int W = SF_IW, WF = SF_IW + 40;
+    band.assign((size_t)(2 * W + 1) * n, 0.0);
+    std::vector<double> yv(WF + 1), xv(2 * WF + 1);
+    for (int j = 0; j < n; ++j) {
+        const int hi = (j + WF < n - 1) ? j + WF : n - 1;
+        const int lo = (j - WF > 0) ? j - WF : 0;
+        yv[0] = 1.0;
+        for (int i = j + 1; i <= hi; ++i) {
+            double v = 0.0;
+            for (int k = 1; k <= SF_KB && i - k >= j; ++k) v -= Lf[(size_t)i * SF_KB + k - 1] * yv[i - k - j];
+            yv[i - j] = v;
+        }
+        // xv index: i - lo
+        for (int i = hi; i >= lo; --i) {
+            double v = (i >= j) ? yv[i - j] : 0.0;
+            for (int k = 1; k <= SF_KB && i + k <= hi; ++k) v -= Uf[(size_t)i * SF_KB + k - 1] * xv[i + k - lo];
+            xv[i - lo] = v * rdiag[i];
+        }
+        const int ilo = (j - W > 0) ? j - W : 0, ihi = (j + W < n - 1) ? j + W : n - 1;
+        for (int i = ilo; i <= ihi; ++i) band[(size_t)(j - i + W) * n + i] = xv[i - lo];
+    }
+}
+
 static void make_twiddles(int nf, std::vector<double>& tw) {
     tw.resize((size_t)nf);  // nf/2 complex values
     for (int k = 0; k < nf / 2; ++k) {
@@ -260,7 +288,7 @@ struct sf_ctx {
     int n = 0, nf = 0, m = 0, P = 0, M = 0, npad = 0, lda = 0, mpad = 0, rows = 0;
     int monotonic = 1;
     double dv = 0.0, wave_max = 0.0;
-    DevBuf wave, flux, sigma, knots, spec, tw, Lf, Uf, rdiag, coef_static;
+    DevBuf wave, flux, sigma, knots, spec, tw, Lf, Uf, rdiag, coef_static, inv_band;
     DevBuf grid, variances, lengthscales, gmin, gmax, alpha, Linv;
 };
 
@@ -389,6 +417,11 @@ extern "C" sf_ctx* sf_ctx_create(const sf_order_desc* d, int device, int* err) {
     TRY(c->Lf.upload(Lf.data(), sizeof(double) * Lf.size()));
     TRY(c->Uf.upload(Uf.data(), sizeof(double) * Uf.size()));
     TRY(c->rdiag.upload(rdiag.data(), sizeof(double) * rdiag.size()));
+    {
+        std::vector<double> band;
+        truncated_inverse_band(d->nf, Lf, Uf, rdiag, band);
+        TRY(c->inv_band.upload(band.data(), sizeof(double) * band.size()));
+    }
     make_twiddles(d->nf, tw);
     TRY(c->tw.upload(tw.data(), sizeof(double) * tw.size()));
 
@@ -472,7 +505,7 @@ struct Carve {
     }
 };
 struct Work {
-    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf;
+    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *ybro, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf;
     double2* fft;
     int *info_e, *info_c;
     unsigned char* tilemap;
@@ -491,6 +524,7 @@ static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, siz
     w.info_e = k.take<int>(b);
     w.info_c = k.take<int>(b);
     w.coef = mdl->has_vsini ? k.take<double>(b * c->nf * c->rows) : nullptr;
+    w.ybro = mdl->has_vsini ? k.take<double>(b * c->nf * c->rows) : nullptr;  // broadened rows before the fit
     const size_t fb = mdl->has_vsini ? sf_fft_scratch_bytes(B * c->rows, c->nf) : 0;
     w.fft = fb ? k.take<double2>(fb / sizeof(double2)) : nullptr;
     w.Xraw = k.take<double>(b * c->m * c->npad);
@@ -557,7 +591,7 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
         a.pstride = pstride;
         a.poff = 0;
         a.scalar_param = 0.0;
-        a.out = w.coef;
+        a.out = w.ybro;
         a.ob = (int64_t)c->nf * c->rows;
         a.orow = 1;
         a.oelem = c->rows;
@@ -565,8 +599,8 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
         a.info = w.info_e;
         rc = sf_launch_broaden(a, s);
         if (rc) return rc;
-        rc = sf_launch_spline_solve(w.coef, B, c->rows, (int64_t)c->nf * c->rows, 1, c->rows, c->nf,
-                                    c->Lf.as<double>(), c->Uf.as<double>(), c->rdiag.as<double>(), s);
+        // spline coefficients of the broadened rows: truncated-inverse band product (fully parallel)
+        rc = sf_launch_spline_apply(w.ybro, w.coef, B, c->rows, c->nf, c->inv_band.as<double>(), s);
         if (rc) return rc;
         coef = w.coef;
     }

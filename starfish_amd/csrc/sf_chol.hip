@@ -118,6 +118,55 @@ __global__ __launch_bounds__(NTH, (NTH == 256) ? 2 : NTH / 128) void k_gemm_nt(s
     const int wm = w / WN, wn = w % WN;  // rows wm*32.., cols wn*(16*TN)..
     const int l15 = lane & 15, lq = lane >> 4;
 
+    // ---- global -> register -> LDS staging: thread covers rows lr+64p, two doubles at column lc.
+    // Rows past the block edge are CLAMPED to the last valid row instead of being predicated: the
+    // duplicated data only feeds accumulator rows / columns that are never stored, and the loads stay
+    // branch-free (a predicated load makes hipcc wait for the whole vm queue).
+    const int lr = tid >> 3, lc = (tid & 7) * 2;
+    const double* Ap[NP];
+    const double* Bp[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        Ap[p] = g.A + (int64_t)b * g.sA + (int64_t)(row0 + min(lr + RPP * p, rows_here - 1)) * g.lda + lc;
+        Bp[p] = g.B + (int64_t)b * g.sB + (int64_t)(col0 + min(lr + RPP * p, cols_here - 1)) * g.ldb + lc;
+    }
+    double2 ra[NP], rb[NP];
+    const bool do_rhs = RHS && g.rhs && (tm == tn);
+    const double* zg = do_rhs ? g.z + (int64_t)b * g.sz + lc : nullptr;
+    double2 zv = make_double2(0.0, 0.0);
+    double part[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) part[p] = 0.0;
+
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            ra[p] = *(const double2*)(Ap[p] + kt * GK);
+            rb[p] = *(const double2*)(Bp[p] + kt * GK);
+        }
+        if (RHS && do_rhs) zv = *(const double2*)(zg + kt * GK);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            double* pa = &As[buf][(lr + RPP * p) * GLD + lc];
+            double* pb = &Bs[buf][(lr + RPP * p) * GLD + lc];
+            pa[0] = ra[p].x;
+            pa[1] = ra[p].y;
+            pb[0] = rb[p].x;
+            pb[1] = rb[p].y;
+        }
+        if (RHS && do_rhs) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) part[p] += rb[p].x * zv.x + rb[p].y * zv.y;
+        }
+    };
+
+    // the first operand slab is requested before the accumulators are initialised so that both
+    // latencies overlap (matters for the short-K launches)
+    const int nk = Kt / GK;
+    if (nk > 0) gload(0);
+
     // ---- accumulators start as the C tile (read, or generated from Y when it was never materialised)
     sf_d4 acc[TM][TN];
     const double* Cin = g.Cin ? g.Cin + (int64_t)b * g.sCin + (int64_t)row0 * g.ldcin + col0 : nullptr;
@@ -163,55 +212,7 @@ __global__ __launch_bounds__(NTH, (NTH == 256) ? 2 : NTH / 128) void k_gemm_nt(s
             }
     }
 
-    // ---- global -> register -> LDS staging: thread covers rows lr+64p, two doubles at column lc.
-    // Rows past the block edge are CLAMPED to the last valid row instead of being predicated: the
-    // duplicated data only feeds accumulator rows / columns that are never stored, and the loads stay
-    // branch-free (a predicated load makes hipcc wait for the whole vm queue).
-    const int lr = tid >> 3, lc = (tid & 7) * 2;
-    const double* Ap[NP];
-    const double* Bp[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        Ap[p] = g.A + (int64_t)b * g.sA + (int64_t)(row0 + min(lr + RPP * p, rows_here - 1)) * g.lda + lc;
-        Bp[p] = g.B + (int64_t)b * g.sB + (int64_t)(col0 + min(lr + RPP * p, cols_here - 1)) * g.ldb + lc;
-    }
-    double2 ra[NP], rb[NP];
-    const bool do_rhs = RHS && g.rhs && (tm == tn);
-    const double* zg = do_rhs ? g.z + (int64_t)b * g.sz + lc : nullptr;
-    double2 zv = make_double2(0.0, 0.0);
-    double part[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) part[p] = 0.0;
-
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            ra[p] = *(const double2*)(Ap[p] + kt * GK);
-            rb[p] = *(const double2*)(Bp[p] + kt * GK);
-        }
-        if (RHS && do_rhs) zv = *(const double2*)(zg + kt * GK);
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            double* pa = &As[buf][(lr + RPP * p) * GLD + lc];
-            double* pb = &Bs[buf][(lr + RPP * p) * GLD + lc];
-            pa[0] = ra[p].x;
-            pa[1] = ra[p].y;
-            pb[0] = rb[p].x;
-            pb[1] = rb[p].y;
-        }
-        if (RHS && do_rhs) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) part[p] += rb[p].x * zv.x + rb[p].y * zv.y;
-        }
-    };
-
-    const int nk = Kt / GK;
-    if (nk > 0) {
-        gload(0);
-        lstore(0);
-    }
+    if (nk > 0) lstore(0);
     __syncthreads();
 
     auto compute = [&](int cur) {

@@ -4,6 +4,7 @@
 
 #define SF_KB 5      // sub/super-diagonals stored for the quintic collocation LU
 #define SF_MAX_M 32  // eigenspectra handled by the per-pixel rank-m factor kernel
+#define SF_IW 64     // half-width of the truncated inverse of the collocation matrix (decay ~0.43^k: < 1e-23)
 
 struct sf_broaden_args {
     const double* in;      // rows x nf real input (free functions) or NULL
@@ -27,6 +28,8 @@ int sf_launch_rfft_rows(const double* in, int rows, int nf, const double2* tw, d
 int sf_launch_spline_solve(double* data, int B, int rows, int64_t bstride, int64_t rstride,
                            int64_t estride, int n, const double* Lf, const double* Uf, const double* rdiag,
                            hipStream_t s);
+// c = A^-1 y with the truncated (banded) inverse: y, c laid out [B][n][rows]; band[(2*SF_IW+1)][n]
+int sf_launch_spline_apply(const double* y, double* c, int B, int rows, int n, const double* band, hipStream_t s);
 int sf_launch_spline_eval(const double* coef, int rows, int ncoef, const double* t, const double* xq, int nq,
                           double* out, hipStream_t s);
 
