@@ -49,6 +49,7 @@ extern "C" {
 #define SF_INFO_OUT_OF_GRID (-1) /* emulator queried outside its grid: emulator.py:377-378 */
 #define SF_INFO_BAD_VSINI (-2)   /* vsini <= 0: transforms.py:121-122 */
 #define SF_INFO_BAD_WEIGHT_COV (-3) /* Sigma_w not positive definite: spectrum_model.py:334 */
+#define SF_INFO_BANDWIDTH (-4)   /* banded solver only: covariance support wider than the given half-width */
 
 #define SF_JITTER 1e-10 /* spectrum_model.py:399 */
 
@@ -210,6 +211,33 @@ int sf_loglike_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const doubl
                      double* d_lnl, double* d_logdet, double* d_sqmah, double* d_resid,
                      double* d_log_scale, int* d_info, void* d_work, size_t work_bytes,
                      void* stream);
+
+/* ---- structure-exploiting solver -----------------------------------
+ * Same value as sf_loglike_batch, computed without ever forming the N x N matrix: the covariance of
+ * spectrum_model.py:334-363 is  C = Bd + Y^T Y  with Bd = sigma^2 + K_global + K_local + jitter
+ * banded (the `r <= r0` masks of models/kernels.py:33,78 give it a half-width of ~6 ls/dv pixels)
+ * and Y^T Y = X^T Sigma_w^-1 X of rank m, so a banded Cholesky plus the m x m Woodbury capacitance
+ * matrix give logdet C and R^T C^-1 R in O(N W^2) flops.  `halfwidth` is the caller's bound W on
+ * max |i-j| over the non-zero entries of Bd (in pixels, over the whole batch); walkers whose
+ * support is wider get info = SF_INFO_BANDWIDTH and lnl = -inf and must be re-run through
+ * sf_loglike_batch.  Requires a strictly increasing wavelength grid and
+ * halfwidth <= sf_banded_max_halfwidth(ctx).  Results agree with the dense path to rounding
+ * (different summation order), not bit for bit. */
+int sf_banded_max_halfwidth(const sf_ctx* ctx);
+size_t sf_banded_workspace_bytes(const sf_ctx* ctx, const sf_model_desc* model, int B, int halfwidth);
+int sf_loglike_banded_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const double* d_params,
+                            int halfwidth, double* d_lnl, double* d_logdet, double* d_sqmah,
+                            double* d_resid, double* d_log_scale, int* d_info, void* d_work,
+                            size_t work_bytes, void* stream);
+
+/* Stand-alone banded kernel: for `batch` symmetric positive definite band matrices in lower band
+ * storage d_band[b*stride + i*ldb + d] = A[i][i-d] (0 <= d <= halfwidth) and nrhs (<= 48) right-hand
+ * sides d_rhs[b*rhs_stride + r*ldr + i], returns d_logdet[b] = log det A and
+ * d_gram[b][r][c] = rhs_r^T A^-1 rhs_c (nrhs x nrhs, row-major).  d_info[b] (zeroed by the call) =
+ * 1-based column of the first non-positive pivot.  (scipy.linalg.cholesky_banded + solves.) */
+int sf_band_logdet_gram_batch(const double* d_band, int n, int halfwidth, int ldb, int64_t stride,
+                              int batch, const double* d_rhs, int nrhs, int ldr, int64_t rhs_stride,
+                              double* d_logdet, double* d_gram, int* d_info, void* stream);
 
 /* Timing hooks for bench.py (process-global, not thread-safe): when enabled, the batched calls
  * record HIP events on the caller's stream around each stage and around every MFMA update launch.

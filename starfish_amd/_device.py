@@ -13,7 +13,10 @@ INFO_MESSAGES = {
     -1: "Querying emulator outside of original parameter range.",
     -2: "vsini must be positive",
     -3: "emulator weight covariance is not positive definite",
+    -4: "covariance support wider than the band half-width given to the banded solver",
 }
+INFO_BANDWIDTH = -4
+C_KMS = 2.99792458e5
 
 
 def _torch():
@@ -154,11 +157,79 @@ class DeviceOrder:
     def release_workspace(self):
         self._ws = None
 
+    # ------------------------------------------------------------------ structure-exploiting solver
+    def banded_max_halfwidth(self):
+        """Largest band half-width (pixels) sf_loglike_banded_batch accepts for this order; -1 = unusable."""
+        return int(self.lib.sf_banded_max_halfwidth(self.ctx)) if self.n else -1
+
+    def _spacing(self):
+        """Smallest velocity step between neighbouring pixels in the metric of the global kernel
+        (Starfish/models/kernels.py:27) -- turns a taper radius in km/s into a bound in pixels."""
+        if getattr(self, "_dv_min", None) is None:
+            w = self._keep[0]
+            self._dv_min = float(np.min(C_KMS / 2 * (w[1:] - w[:-1]) / (w[1:] + w[:-1]))) if self.n > 1 else np.inf
+            self._mono = bool(self.n > 1 and np.all(np.diff(w) > 0))
+        return self._dv_min
+
+    def halfwidth_bound(self, md, rows):
+        """Per-walker upper bound on max|i-j| over the non-zero entries of the structured part of the
+        covariance (global Matern taper r0 = 6 ls, kernels.py:29; local patches r0 = 4 sigma, kernels.py:73),
+        from the host copy of the parameter rows.  Conservative: uses the smallest pixel spacing."""
+        rows = np.atleast_2d(np.asarray(rows, dtype=np.float64))
+        dv = self._spacing()
+        if not self._mono:
+            return np.full(rows.shape[0], np.iinfo(np.int32).max, dtype=np.int64)
+        w = self._keep[0]
+        hw = np.zeros(rows.shape[0])
+        if md.has_global:
+            r0 = 6 * np.exp(rows[:, 5])
+            # r(i, i+d) >= d * dv * (1 - O(r0/c)): the metric is slightly sub-additive
+            hw = np.maximum(hw, np.floor(r0 / dv * (1 + 4 * r0 / C_KMS + 1e-9)) + 1)
+        off = 6 + self.P + md.n_cheb
+        for k in range(md.n_local):
+            mu = rows[:, off + 3 * k]
+            r0 = 4 * np.exp(rows[:, off + 3 * k + 2])
+            # metric d_i = c/mu |w_i - mu| (kernels.py:69): patch = pixels with d_i <= r0; its extent in
+            # pixels is at most 2 r0 / (smallest step of d), step of d >= (c/mu) * min(diff(w))
+            step = C_KMS / np.abs(mu) * float(np.min(np.diff(w)))
+            hw = np.maximum(hw, np.floor(2 * r0 / step * (1 + 1e-9)) + 1)
+        return np.minimum(hw, np.iinfo(np.int32).max).astype(np.int64)
+
+    def banded_workspace_bytes(self, md, B, halfwidth):
+        return self.lib.sf_banded_workspace_bytes(self.ctx, C.byref(md), int(B), int(halfwidth))
+
+    def _work_banded(self, md, B, halfwidth):
+        need = self.banded_workspace_bytes(md, B, halfwidth)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = workspace(need, self.dev)
+        return self._ws
+
+    def loglike_banded_device(self, md, P_dev, halfwidth, out_lnl, info=None, logdet=None, sqmah=None,
+                              resid=None, log_scale=None):
+        """Enqueue-only banded + rank-m solve (sf_loglike_banded_batch); device tensors in/out."""
+        B = int(P_dev.shape[0])
+        ws = self._work_banded(md, B, halfwidth)
+        rc = self.lib.sf_loglike_banded_batch(
+            self.ctx, C.byref(md), B, ptr(P_dev), int(halfwidth), ptr(out_lnl), ptr(logdet), ptr(sqmah),
+            ptr(resid), ptr(log_scale), ptr(info), ptr(ws), ws.numel(), stream_ptr(self.dev),
+        )
+        _lib.check(rc, "sf_loglike_banded_batch")
+
     # ------------------------------------------------------------------ batched calls
-    def loglike(self, md, params, want_resid=False, max_chunk=None):
+    def loglike(self, md, params, want_resid=False, max_chunk=None, solver="dense"):
         """params: (B, stride) float64 (numpy or cuda tensor) in the C-ABI row layout.
-        Returns dict of numpy arrays: lnl, logdet, sqmah, log_scale, info (+ resid)."""
+        Returns dict of numpy arrays: lnl, logdet, sqmah, log_scale, info (+ resid).
+
+        solver: "dense"  -- the reference's algorithm, batched N x N Cholesky (sf_loglike_batch);
+                "banded" -- band + rank-m Woodbury solve (sf_loglike_banded_batch); walkers whose
+                            covariance support exceeds the window come back with info = -4;
+                "auto"   -- banded for the walkers whose half-width bound fits, dense for the rest."""
         torch = _torch()
+        if solver not in ("dense", "banded", "auto"):
+            raise ValueError("solver must be 'dense', 'banded' or 'auto'")
+        if solver != "dense":
+            return self._loglike_structured(md, params, want_resid, max_chunk, solver)
         with torch.cuda.device(self.dev):
             P = params if torch.is_tensor(params) else to_dev(params, self.dev)
             B = int(P.shape[0])
@@ -189,6 +260,50 @@ class DeviceOrder:
             if want_resid:
                 out["resid"] = resid.cpu().numpy()
             return out
+
+    def _loglike_structured(self, md, params, want_resid, max_chunk, solver):
+        torch = _torch()
+        rows = params.cpu().numpy() if torch.is_tensor(params) else np.asarray(params, dtype=np.float64)
+        rows = np.atleast_2d(rows)
+        B = rows.shape[0]
+        wmax = self.banded_max_halfwidth()
+        hw = self.halfwidth_bound(md, rows)
+        fits = hw <= wmax
+        if solver == "banded" and not fits.all():
+            # honour the request for the walkers that fit; the others are reported, not silently densified
+            pass
+        out = dict(
+            lnl=np.full(B, -np.inf), logdet=np.full(B, np.nan), sqmah=np.full(B, np.nan),
+            log_scale=np.full(B, np.nan), info=np.full(B, INFO_BANDWIDTH, dtype=np.int32),
+        )
+        if want_resid:
+            out["resid"] = np.full((B, self.n), np.nan)
+        idx = np.nonzero(fits)[0]
+        if idx.size:
+            W = int(hw[idx].max())
+            with torch.cuda.device(self.dev):
+                P = to_dev(rows[idx], self.dev)
+                nb = idx.size
+                lnl, logdet, sqmah, lsc = (empty((nb,), self.dev) for _ in range(4))
+                info = empty((nb,), self.dev, torch.int32)
+                resid = empty((nb, self.n), self.dev) if want_resid else None
+                chunk = min(nb, max_chunk or nb)
+                for lo in range(0, nb, chunk):
+                    hi = min(lo + chunk, nb)
+                    self.loglike_banded_device(
+                        md, P[lo:hi], W, lnl[lo:hi], info[lo:hi], logdet[lo:hi], sqmah[lo:hi],
+                        resid[lo:hi] if want_resid else None, lsc[lo:hi],
+                    )
+                for key, t in (("lnl", lnl), ("logdet", logdet), ("sqmah", sqmah), ("log_scale", lsc), ("info", info)):
+                    out[key][idx] = t.cpu().numpy()
+                if want_resid:
+                    out["resid"][idx] = resid.cpu().numpy()
+        rest = np.nonzero(~fits | (out["info"] == INFO_BANDWIDTH))[0] if solver == "auto" else np.array([], dtype=int)
+        if rest.size:
+            dense = self.loglike(md, rows[rest], want_resid=want_resid, max_chunk=max_chunk, solver="dense")
+            for key in out:
+                out[key][rest] = dense[key]
+        return out
 
     def loglike_device(self, md, P_dev, out_lnl, info=None):
         """Enqueue-only variant for bench.py: device tensors in/out, no synchronisation."""

@@ -109,6 +109,16 @@ SIGNATURES = {
         C.c_int,
         [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
     ),
+    "sf_banded_max_halfwidth": (C.c_int, [_VP]),
+    "sf_banded_workspace_bytes": (C.c_size_t, [_VP, C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "sf_loglike_banded_batch": (
+        C.c_int,
+        [_VP, C.POINTER(ModelDesc), C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_band_logdet_gram_batch": (
+        C.c_int,
+        [_VP, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _VP, C.c_int, C.c_int, C.c_int64, _VP, _VP, _VP, _VP],
+    ),
     "sf_debug_clock_probe": (C.c_int, [_VP, C.c_longlong, _VP]),
     "sf_profile_enable": (C.c_int, [C.c_int]),
     "sf_profile_read": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),

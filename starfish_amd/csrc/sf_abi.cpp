@@ -809,6 +809,109 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
     return SF_OK;
 }
 
+// ------------------------------------------------------------------- structure-exploiting solver
+struct BandWork {
+    double *band, *gram, *logdet_band;
+    int ldb;
+    size_t bytes;
+};
+static BandWork carve_band(const sf_ctx* c, const sf_model_desc* mdl, int B, int halfwidth, void* p, size_t cap,
+                           size_t base_bytes) {
+    Carve k(p, cap);
+    k.off = base_bytes;
+    BandWork w;
+    w.ldb = (halfwidth + 2) & ~1;
+    w.band = k.take<double>((size_t)B * c->npad * w.ldb);
+    w.gram = k.take<double>((size_t)B * (c->m + 1) * (c->m + 1));
+    w.logdet_band = k.take<double>((size_t)B);
+    w.bytes = sf_align_up(k.off, 256);
+    return w;
+}
+extern "C" int sf_banded_max_halfwidth(const sf_ctx* c) {
+    if (!c || !c->n) return SF_EINVAL;
+    return c->monotonic ? sf_band_max_halfwidth(c->m + 1) : -1;
+}
+extern "C" size_t sf_banded_workspace_bytes(const sf_ctx* c, const sf_model_desc* mdl, int B, int halfwidth) {
+    if (model_ok(c, mdl) || B <= 0 || halfwidth < 0) return 0;
+    const size_t base = carve(c, mdl, B, nullptr, 0, false).bytes;
+    return carve_band(c, mdl, B, halfwidth, nullptr, 0, base).bytes;
+}
+extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params,
+                                       int halfwidth, double* d_lnl, double* d_logdet, double* d_sqmah,
+                                       double* d_resid, double* d_log_scale, int* d_info, void* d_work,
+                                       size_t work_bytes, void* stream) {
+    if (model_ok(c, mdl)) return SF_EINVAL;
+    if (B <= 0 || !d_work || !d_lnl) {
+        sf_set_error("sf_loglike_banded_batch: bad batch size / workspace / d_lnl");
+        return SF_EINVAL;
+    }
+    const int wmax = sf_banded_max_halfwidth(c);
+    if (halfwidth < 0 || halfwidth > wmax) {
+        sf_set_error("sf_loglike_banded_batch: half-width %d outside [0, %d] (use sf_loglike_batch)", halfwidth, wmax);
+        return SF_EINVAL;
+    }
+    const size_t base = carve(c, mdl, B, nullptr, 0, false).bytes;
+    const size_t need = carve_band(c, mdl, B, halfwidth, nullptr, 0, base).bytes;
+    if (work_bytes < need) {
+        sf_set_error("workspace too small: have %zu, need %zu", work_bytes, need);
+        return SF_ENOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    Work w = carve(c, mdl, B, d_work, work_bytes, false);
+    BandWork bw = carve_band(c, mdl, B, halfwidth, d_work, work_bytes, base);
+    g_prof.calls += 1;
+    int rc;
+    {
+        ProfScope ps(s, PS_TRANSFORM);
+        rc = run_transforms(c, mdl, B, d_params, w, nullptr, nullptr, d_resid, d_log_scale, true, s);
+        if (rc) return rc;
+    }
+    const int64_t sband = (int64_t)c->npad * bw.ldb;
+    {
+        ProfScope ps(s, PS_FILL);
+        SF_HIP(hipMemsetAsync(w.info_c, 0, sizeof(int) * (size_t)B, s));
+        sf_fill_args f = fill_args(c, mdl, d_params, w);
+        f.C = nullptr;
+        f.lda = 0;
+        f.stride = 0;
+        f.lower_only = 1;
+        f.add_jitter = 1;
+        f.npad = (c->n + 15) / 16 * 16;
+        rc = sf_launch_band_fill(f, B, bw.band, halfwidth + 1, bw.ldb, sband, w.info_c, s);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(s, PS_POTRF);
+        rc = sf_launch_band_forms(bw.band, (c->n + 15) / 16 * 16, halfwidth, bw.ldb, sband, B, w.resid, c->npad,
+                                  w.Y, c->m + 1, c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band, bw.gram,
+                                  w.info_c, s);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(s, PS_SOLVE);
+        rc = sf_launch_woodbury(bw.gram, c->m + 1, B, bw.logdet_band, w.logdet, w.sqmah, w.info_c, s);
+        if (rc) return rc;
+        rc = sf_launch_finish(B, w.logdet, w.sqmah, w.info_e, w.info_c, d_lnl, d_info, s);
+        if (rc) return rc;
+    }
+    if (d_logdet) SF_HIP(hipMemcpyAsync(d_logdet, w.logdet, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, s));
+    if (d_sqmah) SF_HIP(hipMemcpyAsync(d_sqmah, w.sqmah, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return SF_OK;
+}
+
+extern "C" int sf_band_logdet_gram_batch(const double* d_band, int n, int halfwidth, int ldb, int64_t stride,
+                                         int batch, const double* d_rhs, int nrhs, int ldr, int64_t rhs_stride,
+                                         double* d_logdet, double* d_gram, int* d_info, void* stream) {
+    if (!d_band || !d_rhs || !d_logdet || !d_gram || !d_info) {
+        sf_set_error("sf_band_logdet_gram_batch: null pointer");
+        return SF_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SF_HIP(hipMemsetAsync(d_info, 0, sizeof(int) * (size_t)batch, s));
+    return sf_launch_band_forms(d_band, n, halfwidth, ldb, stride, batch, nullptr, 0, d_rhs, nrhs, ldr, rhs_stride,
+                                d_logdet, d_gram, d_info, s);
+}
+
 // --------------------------------------------------------------------- stand-alone entry points
 extern "C" int sf_global_cov(const double* d_wave, int n, double amplitude, double lengthscale, double* d_out,
                              void* stream) {

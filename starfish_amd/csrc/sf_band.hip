@@ -1,0 +1,496 @@
+// Structure-exploiting solver for the likelihood:
+//
+//     C  =  Bd  +  Y^T Y ,      Bd = diag(sigma^2) + K_global + sum K_local + 1e-10 I
+//
+// The reference builds C dense (Starfish/models/spectrum_model.py:334-363) although K_global and
+// K_local are compactly supported (the `r <= r0` masks of Starfish/models/kernels.py:33,78), so Bd is
+// a band matrix of half-width W pixels (24 ls/dv for the global kernel, whose metric is a quarter of
+// the velocity separation) and Y^T Y = X^T Sigma_w^-1 X has rank m.  With
+//     Bd = L L^T (banded),  z = L^-1 R,  Z = L^-1 Y^T,   S = I_m + Z^T Z = L_S L_S^T
+//     logdet C = logdet Bd + logdet S
+//     R^T C^-1 R = z^T z - | L_S^-1 Z^T z |^2                        (Woodbury)
+// only forward substitutions are needed and the cost drops from N^3/3 to O(N W^2) flops per walker.
+//
+// k_band_forms: one workgroup per matrix sweeps the band in 16-column steps over a sliding window of
+// (W+16) rows held in LDS.  The window is stored as 16 x 16 blocks addressed by the UNORDERED pair of
+// ring slots {row block % nbr, column block % nbr}: every live block of the lower triangle has its own
+// slot, nothing is ever shifted, and the footprint is nbr(nbr+1)/2 blocks instead of nbr^2.
+// Per step k (columns 16k .. 16k+15):
+//   S1  the 16 band rows / right-hand-side columns that were prefetched from HBM into registers during
+//       the previous step land in the slots retired by column k-1;
+//   S2  triangular solve against L_kk, one row per thread (L_kk broadcast from LDS);
+//   S3  trailing update of block column k+1 on v_mfma_f64_16x16x4_f64;
+//   S4  wave 0 factorises the diagonal block k+1 in registers (row per lane, v_readlane broadcasts,
+//       v_rsq_f64 + Newton) WHILE the other waves finish the trailing update on the matrix cores,
+//       issue the HBM prefetch for the next rows and accumulate log(pivot).
+// The right-hand sides (residual + the m rows of Y) ride along as extra ROWS of the matrix, so their
+// forward substitution is the same solve/update, and their Gram matrix [z Z]^T [z Z] accumulates in
+// LDS.  L is never written anywhere: the outputs are logdet(Bd) and the (1+m)^2 Gram matrix.
+// k_woodbury then does the m x m capacitance solve.
+#include "sf_common.h"
+
+#define BB 16
+#define BS (BB * (BB + 1))  // doubles per stored block (row stride 17: conflict-free fragment reads)
+#define BLD (BB + 1)
+#define SFB_PF 4            // prefetch registers per thread
+
+struct sf_band_args {
+    const double* band;  // [batch] x sband : band[i*ldb + d] = A[i][i-d], d in [0, halfwidth]
+    int64_t sband;
+    int ldb;
+    int halfwidth;
+    const double* rhs;   // [batch] x srhs : row r of the right-hand sides at rhs + r*ldr (length n)
+    int64_t srhs;
+    int ldr;
+    int nrhs;
+    // optional separate source for row 0 (the residual lives in its own buffer in the fused path);
+    // when given, rows 1.. come from rhs rows 0..
+    const double* rhs0;
+    int64_t srhs0;
+    int n;      // matrix order
+    int nbr;    // window blocks per side
+    double* logdet;  // [batch]
+    double* gram;    // [batch][nrhs*nrhs]
+    int* info;       // [batch] first non-positive pivot (1-based), left untouched otherwise
+    int dbg;         // tuning aid (SF_BAND_DBG bit mask): skip phases
+};
+
+__device__ __forceinline__ double sfb_readlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(p): hardware estimate + two Newton steps (full double precision for p > 0)
+__device__ __forceinline__ double sfb_rsqrt(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    double e = __builtin_fma(-h * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-h * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+
+// Workgroup barrier for LDS data only: the HBM prefetch loads stay in flight across it (the compiler
+// waits for them where their registers are first used).
+__device__ __forceinline__ void sfb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ int sfb_pair(int a, int b) {  // slot of the unordered pair {a, b}
+    return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a;
+}
+
+// One element of block row gb for the initial window fill (generic, off the critical path).
+// e < nbr*256: band blocks (gb, gb-nbr+1 .. gb) row-major inside each block; then NR*16 rhs entries.
+__device__ __noinline__ double sfb_fetch(const double* band, const double* rhs, const double* rhs0, int gb,
+                                         int e, int nbr, int n, int halfwidth, int ldb, int nrhs, int ldr) {
+    const int row_elems = nbr * BB * BB;
+    if (e < row_elems) {
+        const int blk = e >> 8, r = (e >> 4) & 15, cc = e & 15;
+        const int gc = gb - nbr + 1 + blk;
+        const int i = gb * BB + r, d = i - (gc * BB + cc);
+        if (gc < 0 || d < 0) return 0.0;
+        if (i < n) return d <= halfwidth ? band[(int64_t)i * ldb + d] : 0.0;
+        return d == 0 ? 1.0 : 0.0;  // identity padding up to a multiple of 16
+    }
+    const int q = e - row_elems, r = q >> 4, cc = q & 15;
+    const int i = gb * BB + cc;
+    if (i >= n || r >= nrhs) return 0.0;
+    if (rhs0) return r == 0 ? rhs0[i] : rhs[(int64_t)(r - 1) * ldr + i];
+    return rhs[(int64_t)r * ldr + i];
+}
+
+// Thread roles (blockDim = 512, 768 or 1024):
+//   wave 0       diagonal-block factorisation + inverse (S3), its share of the MFMA work elsewhere
+//   waves 1..3   prefetch of the right-hand-side columns, log(pivot), MFMA work
+//   waves 4..    prefetch of the band rows (groups of 256 threads = one 16 x 16 block each), MFMA work
+template <int NRB>
+__global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
+    extern __shared__ double lds[];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int nbr = a.nbr;
+    constexpr int NR = NRB * BB, LDG = NR + 1;
+    double* Wb = lds;                                  // nbr(nbr+1)/2 band blocks
+    double* RH = Wb + (nbr * (nbr + 1) / 2) * BS;      // [NRB][nbr] right-hand-side blocks (column ring)
+    double* Fb = RH + NRB * nbr * BS;                  // inverse of the current diagonal factor, L_kk^-1
+    double* G = Fb + BS;                               // [NR][LDG]   Gram accumulator
+    double* pv = G + NR * LDG;                         // [2][16] pivots (for the log-determinant)
+    double* red = pv + 2 * BB;                         // [16] reduction scratch
+
+    const int n = a.n, W = a.halfwidth;
+    const int nblk = (n + BB - 1) / BB;
+    const double* __restrict__ band = a.band + (int64_t)b * a.sband;
+    const double* __restrict__ rhs = a.rhs + (int64_t)b * a.srhs;
+    const double* __restrict__ rhs0 = a.rhs0 ? a.rhs0 + (int64_t)b * a.srhs0 : nullptr;
+    const int row_elems = nbr * BB * BB, all_elems = row_elems + NR * BB;
+    auto wrap = [&](int slot) { return slot >= nbr ? slot - nbr : slot; };  // slot in [0, 2 nbr)
+
+    // ---- initial window: block rows 0 .. nbr-1
+    for (int gb = 0; gb < nbr; ++gb)
+        for (int e = tid; e < all_elems; e += nthreads) {
+            const double v = sfb_fetch(band, rhs, rhs0, gb, e, nbr, n, W, a.ldb, a.nrhs, a.ldr);
+            if (e < row_elems) {
+                const int blk = e >> 8, gc = gb - nbr + 1 + blk;
+                if (gc >= 0) Wb[sfb_pair(gb, gc) * BS + ((e >> 4) & 15) * BLD + (e & 15)] = v;
+            } else {
+                const int q = e - row_elems, r = q >> 4;
+                RH[((r >> 4) * nbr + gb) * BS + (r & 15) * BLD + (q & 15)] = v;
+            }
+        }
+    for (int e = tid; e < NR * LDG; e += nthreads) G[e] = 0.0;
+
+    const int l15 = lane & 15, lq = lane >> 4;
+    // Wave 0: Cholesky of the 16 x 16 diagonal block AND the inverse of its factor, both kept in the
+    // MFMA accumulator layout (lane (lq, l15), register r <-> element (lq + 4r, l15)).  Column j of the
+    // symmetric block is also its row j = register j/4 of the 16 lanes of quarter j%4, which is exactly
+    // where a K-slice of the MFMA operands lives: the rank-1 elimination  A -= v v^T  and the update of
+    // F = L^-1 (F -= v g^T) are one v_mfma_f64_16x16x4_f64 each, with no data movement at all.
+    int bad = 0;
+    auto potrf16 = [&](int kb, int ks) {  // ks = kb % nbr
+        const double* D = Wb + sfb_pair(ks, ks) * BS;
+        sf_d4 acc, f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = lq + 4 * r;
+            acc[r] = D[max(row, l15) * BLD + min(row, l15)];  // only the lower triangle is maintained
+            f[r] = row == l15 ? 1.0 : 0.0;
+        }
+        __builtin_amdgcn_s_setprio(3);  // the other waves of this SIMD are doing bulk MFMA work
+        double p = sfb_readlane(acc[0], 0);
+#pragma unroll
+        for (int j = 0; j < BB; ++j) {
+            const int qj = j & 3, rj = j >> 2;
+            if (!(p > 0.0) && !bad) bad = kb * BB + j + 1;
+            const double rs = sfb_rsqrt(p);
+            if (lane == 0) pv[(kb & 1) * BB + j] = p;
+            const bool in_q = lq == qj;
+            const double v = (in_q && l15 > j) ? acc[rj] * rs : 0.0;  // l_ij, i = l15 > j
+            const double g = in_q ? f[rj] * rs : 0.0;                 // row j of F, scaled
+            if (in_q) f[rj] = g;
+            if (j + 1 < BB) {
+                // next pivot a_{j+1,j+1} - l_{j+1,j}^2 from scalars, so that its rsqrt chain runs while
+                // the matrix core applies this column's rank-1 update
+                const double an = sfb_readlane(acc[(j + 1) >> 2], ((j + 1) & 3) * 16 + j + 1);
+                const double vn = sfb_readlane(v, qj * 16 + j + 1);
+                p = __builtin_fma(-vn, vn, an);
+            }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, acc, 0, 0, 0);
+            f = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, g, f, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Fb[(lq + 4 * r) * BLD + l15] = f[r];
+    };
+    __syncthreads();
+    if (wave == 0) potrf16(0, 0);
+
+    // prefetch roles: fixed (row, column) inside a block per thread, only the block index varies
+    const int ngroups = (nwaves - 4) >> 2;             // 256-thread groups of band loaders (1..3)
+    const int lt = tid - 256;                          // band loader index (waves >= 4)
+    const int pr = (lt >> 4) & 15, pc = lt & 15, pg = lt >> 8;
+    const int rt = tid - 64;                           // rhs loader index (waves 1..3)
+    double pf[SFB_PF];                                 // prefetched values (band or rhs)
+    int pfcode = 0;                                    // 2 bits per slot: 0 -> 0.0, 1 -> pf, 2 -> 1.0
+    double ld_acc = 0.0;                               // wave 1, lanes 0..15: partial sums of log(pivot)
+    __syncthreads();
+
+    const int nb1 = nbr - 1, RB = nb1 + NRB;
+    long long tacc[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define SFB_TICK(k) if (a.dbg & 256) { const long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; }
+    int ks = 0;  // kb % nbr
+    for (int kb = 0; kb < nblk; ++kb, ks = wrap(ks + 1)) {
+        auto pblock = [&](int I) -> double* {  // row block I below the diagonal block, column kb
+            return I < nb1 ? Wb + sfb_pair(wrap(ks + 1 + I), ks) * BS : RH + ((I - nb1) * nbr + ks) * BS;
+        };
+        // X = P L_kk^-T in place, on the matrix cores (B operand = rows of F = L_kk^-1)
+        auto xsolve = [&](double* P) {
+            sf_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double* Ap = P + l15 * BLD + lq;
+            const double* Bp = Fb + l15 * BLD + lq;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[kk * 4], Bp[kk * 4], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(lq + 4 * r) * BLD + l15] = acc[r];
+        };
+        // Block (I, J), I >= J, of [band rows below ; rhs rows] x [same]:  C -= P_I P_J^T
+        // (Gram blocks: G += Z_I Z_J^T)
+        auto update = [&](int I, int J) {
+            const double* PI = pblock(I);
+            const double* PJ = pblock(J);
+            double* Cb;
+            int ldc = BLD;
+            const bool gram = J >= nb1;
+            if (gram) {
+                Cb = G + ((I - nb1) * BB) * LDG + (J - nb1) * BB;
+                ldc = LDG;
+            } else if (I < nb1) {
+                Cb = Wb + sfb_pair(wrap(ks + 1 + I), wrap(ks + 1 + J)) * BS;
+            } else {
+                Cb = RH + ((I - nb1) * nbr + wrap(ks + 1 + J)) * BS;
+            }
+            sf_d4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = Cb[(lq + 4 * r) * ldc + l15];
+            const double* Ap = PI + l15 * BLD + lq;
+            const double* Bp = PJ + l15 * BLD + lq;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                double av = Ap[kk * 4];
+                if (!gram) av = -av;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bp[kk * 4], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cb[(lq + 4 * r) * ldc + l15] = acc[r];
+        };
+
+        // ---- S1: the prefetched block row kb-1+nbr lands in the slots retired by column kb-1, while
+        //      the row blocks that are already in the window are solved against L_kk
+        if (kb > 0) {
+            const int rs = ks == 0 ? nbr - 1 : ks - 1;
+            if (wave >= 4) {
+#pragma unroll
+                for (int q = 0; q < SFB_PF; ++q) {
+                    const int blk = pg + q * ngroups;
+                    const int code = (pfcode >> (2 * q)) & 3;
+                    if (blk < nbr)
+                        Wb[sfb_pair(rs, wrap(rs + 1 + blk)) * BS + pr * BLD + pc] = code == 1 ? pf[q] : code == 2 ? 1.0 : 0.0;
+                }
+            } else if (wave >= 1) {
+#pragma unroll
+                for (int q = 0; q < SFB_PF; ++q) {
+                    const int e = rt + q * 192;
+                    if (e < NR * BB)
+                        RH[((e >> 8) * nbr + rs) * BS + ((e >> 4) & 15) * BLD + (e & 15)] = ((pfcode >> (2 * q)) & 1) ? pf[q] : 0.0;
+                }
+            }
+        }
+        // all row blocks except the newest band row (index nb1-1, being written right now when kb > 0)
+        for (int I = wave; I < RB; I += nwaves)
+            if (I != nb1 - 1 || kb == 0) xsolve(pblock(I));
+        sfb_barrier();
+        SFB_TICK(0)
+
+        // ---- S2: the newest row block is solved by the wave that owns its update; then block column
+        //      kb+1 of the trailing update (J = 0): the next diagonal block and the next solve need it
+        for (int I = wave; I < RB; I += nwaves) {
+            if (I == nb1 - 1 && kb > 0) xsolve(pblock(I));
+            update(I, 0);
+        }
+        sfb_barrier();
+        SFB_TICK(1)
+
+        // ---- S3: wave 0 -> next diagonal block; the others -> HBM prefetch, rest of the update, log
+        if (wave == 0) {
+            if (kb + 1 < nblk) potrf16(kb + 1, wrap(ks + 1));
+            SFB_TICK(4)
+        } else {
+            if (kb + 1 < nblk) {
+                const int gb = kb + nbr;
+                // straight-line code: all loads are issued back to back and nothing here reads their
+                // results (pfcode says at S1 whether a slot takes the loaded value, 1.0 or 0.0)
+                pfcode = 0;
+                if (wave >= 4) {
+                    const int i = gb * BB + pr;
+                    const double* src = band + (int64_t)i * a.ldb;
+#pragma unroll
+                    for (int q = 0; q < SFB_PF; ++q) {
+                        const int blk = pg + q * ngroups;
+                        const int d = (nbr - 1 - blk) * BB + pr - pc;
+                        const bool ok = blk < nbr && d >= 0 && d <= W && i < n;
+                        const bool one = blk < nbr && d == 0 && i >= n;
+                        pfcode |= (ok ? 1 : one ? 2 : 0) << (2 * q);
+                        pf[q] = *(ok ? src + d : band);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < SFB_PF; ++q) {
+                        const int e = rt + q * 192, r = e >> 4;
+                        const int i = gb * BB + (e & 15);
+                        const bool ok = e < NR * BB && r < a.nrhs && i < n;
+                        const double* src = (rhs0 && r == 0) ? rhs0 + i : rhs + (int64_t)(rhs0 ? r - 1 : r) * a.ldr + i;
+                        pfcode |= (ok ? 1 : 0) << (2 * q);
+                        pf[q] = *(ok ? src : band);
+                    }
+                }
+            }
+            SFB_TICK(2)
+            // pairs (I, J), 1 <= J <= I < RB, in triangular order; wave w takes every (nwaves-1)-th
+            int Ip = 0, Jp = wave - 1;
+            for (;;) {
+                while (Jp > Ip) {
+                    Jp -= Ip + 1;
+                    ++Ip;
+                }
+                if (Ip > RB - 2) break;
+                update(Ip + 1, Jp + 1);
+                Jp += nwaves - 1;
+            }
+            SFB_TICK(4)
+            if (wave == 1 && lane < BB) ld_acc += log(pv[(kb & 1) * BB + lane]);
+        }
+        sfb_barrier();
+        SFB_TICK(3)
+    }
+
+    // ---- outputs
+    if (wave == 1 && lane < BB) red[lane] = ld_acc;
+    __syncthreads();
+    if (tid == 0) {
+        double sum = 0.0;
+        for (int i = 0; i < BB; ++i) sum += red[i];
+        a.logdet[b] = sum;
+        if (bad && a.info && a.info[b] == 0) a.info[b] = bad;
+    }
+    double* out = a.gram + (int64_t)b * a.nrhs * a.nrhs;
+    if (a.dbg & 256) {
+        if ((tid == 0 || tid == 64 || tid == 256 || tid == 960) && b == 0)
+            printf("tid %d prefetch-issue %lld ", tid, tacc[2] / nblk),
+            printf("band_forms cycles/step: S1 %lld S2 %lld S3(wave0 potrf %lld, wait %lld) steps %d\n",
+                   tacc[0] / nblk, tacc[1] / nblk, tacc[4] / nblk, tacc[3] / nblk, nblk);
+    }
+    for (int e = tid; e < a.nrhs * a.nrhs; e += nthreads) {
+        const int r = e / a.nrhs, c = e - r * a.nrhs;
+        out[e] = (c <= r) ? G[r * LDG + c] : G[c * LDG + r];
+    }
+}
+
+// Capacitance step of the Woodbury identity, one wave per walker:
+//   S = I + gram[1:,1:],  S = L_S L_S^T,  u = L_S^-1 gram[1:,0]
+//   logdet = logdet_band + sum log diag(S-pivots),  sqmah = gram[0][0] - u.u
+__global__ __launch_bounds__(64) void k_woodbury(const double* __restrict__ gram, int nrhs,
+                                                 const double* __restrict__ logdet_band,
+                                                 double* __restrict__ logdet, double* __restrict__ sqmah,
+                                                 int* __restrict__ info) {
+    __shared__ double S[33 * 33];
+    __shared__ double u[33];
+    const int b = blockIdx.x, lane = threadIdx.x, m = nrhs - 1;
+    const double* g = gram + (int64_t)b * nrhs * nrhs;
+    for (int e = lane; e < m * m; e += 64) {
+        const int r = e / m, c = e - r * m;
+        S[r * 33 + c] = g[(r + 1) * nrhs + (c + 1)] + (r == c ? 1.0 : 0.0);
+    }
+    if (lane < m) u[lane] = g[(lane + 1) * nrhs];
+    __syncthreads();
+    double ld = 0.0;
+    int bad = 0;
+    for (int j = 0; j < m; ++j) {
+        const double p = S[j * 33 + j];
+        if (!(p > 0.0) && !bad) bad = 1;
+        const double rs = 1.0 / sqrt(p);
+        ld += log(p);
+        __syncthreads();
+        double lij = 0.0;
+        if (lane > j && lane < m) {
+            lij = S[lane * 33 + j] * rs;
+            S[lane * 33 + j] = lij;
+        }
+        if (lane == j) u[j] *= rs;  // forward substitution rides along: u_j = (v_j - ...)/l_jj
+        __syncthreads();
+        if (lane > j && lane < m) {
+            for (int c = j + 1; c <= lane; ++c) S[lane * 33 + c] -= lij * S[c * 33 + j];
+            u[lane] -= lij * u[j];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        double uu = 0.0;
+        for (int j = 0; j < m; ++j) uu += u[j] * u[j];
+        logdet[b] = logdet_band[b] + ld;
+        sqmah[b] = g[0] - uu;
+        if (bad && info && info[b] == 0) info[b] = SF_INFO_BAD_WEIGHT_COV;
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+static size_t band_lds_bytes(int nbr, int nrb) {
+    const size_t nr = (size_t)nrb * BB;
+    return sizeof(double) * ((size_t)nbr * (nbr + 1) / 2 * BS + (size_t)nrb * nbr * BS + BS + nr * (nr + 1) + 3 * BB);
+}
+
+static int band_nbr(int halfwidth) {  // window rows >= W + 16, and at least three blocks (see S2)
+    const int nbr = (halfwidth + 2 * BB - 1) / BB;
+    return nbr < 3 ? 3 : nbr;
+}
+
+int sf_band_max_halfwidth(int nrhs) {
+    const int nrb = (nrhs + BB - 1) / BB;
+    int best = -1;
+    for (int w = 0; w <= 4096; w += BB) {
+        if (band_lds_bytes(band_nbr(w), nrb) <= 160 * 1024) best = w;
+        else break;
+    }
+    return best;
+}
+
+int sf_launch_band_forms(const double* band, int n, int halfwidth, int ldb, int64_t sband, int batch,
+                         const double* rhs0, int64_t srhs0, const double* rhs, int nrhs, int ldr,
+                         int64_t srhs, double* logdet, double* gram, int* info, hipStream_t s) {
+    const int nrb = (nrhs + BB - 1) / BB;
+    if (n <= 0 || batch <= 0 || halfwidth < 0 || ldb < halfwidth + 1 || nrhs < 1 || nrb > 3) {
+        sf_set_error("band_forms: bad arguments (n=%d halfwidth=%d ldb=%d nrhs=%d)", n, halfwidth, ldb, nrhs);
+        return SF_EINVAL;
+    }
+    const int nbr = band_nbr(halfwidth);
+    const size_t shm = band_lds_bytes(nbr, nrb);
+    if (shm > 160 * 1024) {
+        sf_set_error("band_forms: half-width %d with %d right-hand sides exceeds the LDS window (max %d)",
+                     halfwidth, nrhs, sf_band_max_halfwidth(nrhs));
+        return SF_EINVAL;
+    }
+    sf_band_args a;
+    a.band = band;
+    a.sband = sband;
+    a.ldb = ldb;
+    a.halfwidth = halfwidth;
+    a.rhs = rhs;
+    a.srhs = srhs;
+    a.ldr = ldr;
+    a.nrhs = nrhs;
+    a.rhs0 = rhs0;
+    a.srhs0 = srhs0;
+    a.n = n;
+    a.nbr = nbr;
+    a.logdet = logdet;
+    a.gram = gram;
+    a.info = info;
+    static const int dbg = getenv("SF_BAND_DBG") ? atoi(getenv("SF_BAND_DBG")) : 0;
+    a.dbg = dbg;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    // waves 4.. prefetch the band rows in groups of 256 threads (one 16 x 16 block per group and
+    // register): enough groups for SFB_PF registers to cover the nbr blocks of a block row
+    int nwaves = nbr <= SFB_PF ? 8 : nbr <= 2 * SFB_PF ? 12 : 16;
+    static const int force_waves = getenv("SF_BAND_WAVES") ? atoi(getenv("SF_BAND_WAVES")) : 0;
+    if (force_waves) nwaves = force_waves;
+    if (nwaves < 8 || nwaves > 16 || (nwaves & 3) || ((nwaves - 4) / 4) * SFB_PF < nbr ||
+        nwaves * 64 < (nbr - 1 + nrb) * BB) {
+        sf_set_error("band_forms: window too large for one workgroup");
+        return SF_EINVAL;
+    }
+    const dim3 blk(nwaves * 64);
+    if (nrb == 1) hipLaunchKernelGGL(k_band_forms<1>, dim3(batch), blk, shm, s, a);
+    else if (nrb == 2) hipLaunchKernelGGL(k_band_forms<2>, dim3(batch), blk, shm, s, a);
+    else hipLaunchKernelGGL(k_band_forms<3>, dim3(batch), blk, shm, s, a);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_woodbury(const double* gram, int nrhs, int batch, const double* logdet_band, double* logdet,
+                       double* sqmah, int* info, hipStream_t s) {
+    if (nrhs < 1 || nrhs > 33) {
+        sf_set_error("woodbury: 0..32 low-rank rows supported");
+        return SF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_woodbury, dim3(batch), dim3(64), 0, s, gram, nrhs, logdet_band, logdet, sqmah, info);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}

@@ -76,6 +76,17 @@ struct sf_fill_args {
     int nt128;
 };
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);
+// band storage of the structured part of C (sf_band.hip consumes it); a.npad = rows written (>= a.n)
+int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int ldb, int64_t sband, int* info,
+                        hipStream_t s);
 int sf_launch_global_cov(const double* wave, int n, double amp, double ls, double* out, hipStream_t s);
 int sf_launch_local_cov(const double* wave, int n, double amp, double mu, double sigma, int accumulate,
                         double* out, hipStream_t s);
+
+// sf_band.hip: banded Cholesky + forward substitution of (1 + m) right-hand sides -> logdet, Gram matrix
+int sf_band_max_halfwidth(int nrhs);
+int sf_launch_band_forms(const double* band, int n, int halfwidth, int ldb, int64_t sband, int batch,
+                         const double* rhs0, int64_t srhs0, const double* rhs, int nrhs, int ldr,
+                         int64_t srhs, double* logdet, double* gram, int* info, hipStream_t s);
+int sf_launch_woodbury(const double* gram, int nrhs, int batch, const double* logdet_band, double* logdet,
+                       double* sqmah, int* info, hipStream_t s);

@@ -297,6 +297,91 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
     return SF_OK;
 }
 
+// Band storage of Bd = diag(sigma^2) + K_global + sum K_local + jitter for the structure-exploiting
+// solver (sf_band.hip): band[i*ldb + d] = Bd[i][i-d], d in [0, ws).  The element formulas and their
+// order of additions are those of k_fill_band.  A thread on the last stored diagonal also probes the
+// first diagonal outside the storage: a non-zero there means the caller's half-width is too small
+// for this walker -> info = SF_INFO_BANDWIDTH (the result would silently drop covariance otherwise).
+__global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __restrict__ band, int ws, int ldb,
+                                                   int64_t sband, int* __restrict__ info) {
+    // per-walker constants once per block: exp() of the hyper-parameters (spectrum_model.py:343-357)
+    __shared__ double s_glob[2];
+    __shared__ double s_loc[SF_MAX_LOCAL][3];
+    const int b = blockIdx.y;
+    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
+    if (threadIdx.x < 2 && a.has_global) s_glob[threadIdx.x] = exp(P[a.off_global + threadIdx.x]);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * a.n_local) {
+        const int q = threadIdx.x - 64, k = q / 3, f = q - 3 * k;
+        const double v = P[a.off_local + q];
+        s_loc[k][f] = f == 0 ? v : exp(v);
+    }
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)a.npad * ws) return;
+    const int i = (int)(e / ws), d = (int)(e - (int64_t)i * ws);
+    const int j = i - d;
+    double v = 0.0;
+    if (i >= a.n) {
+        v = (d == 0) ? 1.0 : 0.0;
+    } else if (j >= 0) {
+        const double w_row = a.wave[i];
+        auto structured = [&](int col, bool& any) {
+            const double w_col = a.wave[col];
+            double acc = 0.0;
+            if (a.has_global) {
+                const double g = sf_matern_elem(w_row, w_col, s_glob[0], s_glob[1], 6 * s_glob[1]);
+                acc = g;
+                any = any || g != 0.0;
+            }
+            if (a.n_local > 0) {
+                double loc = 0.0;
+                for (int k = 0; k < a.n_local; ++k) {
+                    const double mu = s_loc[k][0], amp = s_loc[k][1], sig = s_loc[k][2];
+                    const double l = sf_local_elem(sf_local_metric(w_row, mu), sf_local_metric(w_col, mu), amp,
+                                                   sig, 4 * sig);
+                    loc = loc + l;
+                    any = any || l != 0.0;
+                }
+                acc = acc + loc;
+            }
+            return acc;
+        };
+        bool any = false;
+        const double k = structured(j, any);
+        if (d == 0) {
+            const double sg = a.sigma[i];
+            v = sg * sg;
+            v = v + k;
+            if (a.add_jitter) v = v + SF_JITTER;
+        } else {
+            v = k;
+        }
+        if (d == ws - 1 && j >= 1) {
+            bool outside = false;
+            (void)structured(j - 1, outside);
+            if (outside) atomicCAS(info + b, 0, SF_INFO_BANDWIDTH);
+        }
+    }
+    band[(int64_t)b * sband + (int64_t)i * ldb + d] = v;
+}
+
+int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int ldb, int64_t sband, int* info,
+                        hipStream_t s) {
+    if (a.n_local > SF_MAX_LOCAL) {
+        sf_set_error("at most %d local kernels are supported", SF_MAX_LOCAL);
+        return SF_EINVAL;
+    }
+    if (!a.monotonic) {
+        sf_set_error("the banded solver needs a strictly increasing wavelength grid");
+        return SF_EINVAL;
+    }
+    const int64_t total = (int64_t)a.npad * ws;
+    hipLaunchKernelGGL(k_band_fill, dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, s, a, band, ws, ldb,
+                       sband, info);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
 // ------------------------------------------------------------ stand-alone kernels (free functions)
 __global__ __launch_bounds__(256) void k_global_cov(const double* __restrict__ wave, int n, double amp,
                                                     double ls, double* __restrict__ out) {
