@@ -15,18 +15,22 @@
 // (W+16) rows held in LDS.  The window is stored as 16 x 16 blocks addressed by the UNORDERED pair of
 // ring slots {row block % nbr, column block % nbr}: every live block of the lower triangle has its own
 // slot, nothing is ever shifted, and the footprint is nbr(nbr+1)/2 blocks instead of nbr^2.
-// Per step k (columns 16k .. 16k+15):
-//   S1  the 16 band rows / right-hand-side columns that were prefetched from HBM into registers during
-//       the previous step land in the slots retired by column k-1;
-//   S2  triangular solve against L_kk, one row per thread (L_kk broadcast from LDS);
-//   S3  trailing update of block column k+1 on v_mfma_f64_16x16x4_f64;
-//   S4  wave 0 factorises the diagonal block k+1 in registers (row per lane, v_readlane broadcasts,
-//       v_rsq_f64 + Newton) WHILE the other waves finish the trailing update on the matrix cores,
-//       issue the HBM prefetch for the next rows and accumulate log(pivot).
+// Everything runs on v_mfma_f64_16x16x4_f64.  Per step k (columns 16k .. 16k+15), two barriers:
+//   X  the 16 band rows / right-hand-side columns that were prefetched from HBM into registers during
+//      the previous step land in the slots retired by column k-1; block column k+1 of the trailing
+//      update is applied (the wave that owns the newest row first solves it against L_kk);
+//   S  wave 0 factorises the diagonal block k+1 AND inverts its factor in the MFMA accumulator layout
+//      (one rank-1 MFMA per column each, pivots from scalars so that the rsqrt chain overlaps the
+//      matrix core) WHILE the other waves issue the next HBM prefetch, finish the trailing update and
+//      accumulate log(pivot); whoever is done waits on an LDS flag for the factor and solves its share
+//      of block column k+1 (X = P L^-T as a product with the explicit 16 x 16 inverse).
 // The right-hand sides (residual + the m rows of Y) ride along as extra ROWS of the matrix, so their
 // forward substitution is the same solve/update, and their Gram matrix [z Z]^T [z Z] accumulates in
 // LDS.  L is never written anywhere: the outputs are logdet(Bd) and the (1+m)^2 Gram matrix.
 // k_woodbury then does the m x m capacitance solve.
+// Measured on MI355X (cfg 2, W = 141 px, 16 waves): 1.5 ms for 128 matrices = one CU each; the
+// sequential diagonal-block chain (~5.5k cycles per step) and the per-CU fp64 MFMA rate (64 cycles
+// per 16x16x4, 55 blocks x 4 per step) bound it; the other half of the chip is idle at B = 128.
 #include "sf_common.h"
 
 #define BB 16
@@ -52,7 +56,6 @@ struct sf_band_args {
     double* logdet;  // [batch]
     double* gram;    // [batch][nrhs*nrhs]
     int* info;       // [batch] first non-positive pivot (1-based), left untouched otherwise
-    int dbg;         // tuning aid (SF_BAND_DBG bit mask): skip phases
 };
 
 __device__ __forceinline__ double sfb_readlane(double v, int lane) {
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
     double* G = Fb + BS;                               // [NR][LDG]   Gram accumulator
     double* pv = G + NR * LDG;                         // [2][16] pivots (for the log-determinant)
     double* red = pv + 2 * BB;                         // [16] reduction scratch
+    volatile int* sync = (volatile int*)(red + BB);   // [0] diagonal factor ready (kb+1), [1] waves that placed block 0
 
     const int n = a.n, W = a.halfwidth;
     const int nblk = (n + BB - 1) / BB;
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
             }
         }
     for (int e = tid; e < NR * LDG; e += nthreads) G[e] = 0.0;
+    if (tid < 2) sync[tid] = 0;
 
     const int l15 = lane & 15, lq = lane >> 4;
     // Wave 0: Cholesky of the 16 x 16 diagonal block AND the inverse of its factor, both kept in the
@@ -160,12 +165,12 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
         }
         __builtin_amdgcn_s_setprio(3);  // the other waves of this SIMD are doing bulk MFMA work
         double p = sfb_readlane(acc[0], 0);
+        double pkeep = 1.0;  // lane j keeps pivot j: one LDS store and one sign test after the loop
 #pragma unroll
         for (int j = 0; j < BB; ++j) {
             const int qj = j & 3, rj = j >> 2;
-            if (!(p > 0.0) && !bad) bad = kb * BB + j + 1;
+            pkeep = lane == j ? p : pkeep;
             const double rs = sfb_rsqrt(p);
-            if (lane == 0) pv[(kb & 1) * BB + j] = p;
             const bool in_q = lq == qj;
             const double v = (in_q && l15 > j) ? acc[rj] * rs : 0.0;  // l_ij, i = l15 > j
             const double g = in_q ? f[rj] * rs : 0.0;                 // row j of F, scaled
@@ -180,6 +185,9 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, acc, 0, 0, 0);
             f = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, g, f, 0, 0, 0);
         }
+        if (lane < BB) pv[(kb & 1) * BB + lane] = pkeep;
+        const unsigned long long neg = __ballot(lane < BB && !(pkeep > 0.0));
+        if (neg && !bad) bad = kb * BB + __ffsll((long long)neg);
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Fb[(lq + 4 * r) * BLD + l15] = f[r];
@@ -198,57 +206,63 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
     __syncthreads();
 
     const int nb1 = nbr - 1, RB = nb1 + NRB;
-    long long tacc[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#define SFB_TICK(k) if (a.dbg & 256) { const long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; }
+    auto spin_until = [&](int which, int target) {
+        while (sync[which] < target) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    // helpers on column block kb (ring slot ks)
+    auto pblock_at = [&](int ks_, int I) -> double* {  // row block I below the diagonal block
+        return I < nb1 ? Wb + sfb_pair(wrap(ks_ + 1 + I), ks_) * BS : RH + ((I - nb1) * nbr + ks_) * BS;
+    };
+    // X = P L_kk^-T in place, on the matrix cores (B operand = rows of F = L_kk^-1)
+    auto xsolve = [&](double* P) {
+        sf_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* Ap = P + l15 * BLD + lq;
+        const double* Bp = Fb + l15 * BLD + lq;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[kk * 4], Bp[kk * 4], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[(lq + 4 * r) * BLD + l15] = acc[r];
+    };
+    // Block (I, J), I >= J, of [band rows below ; rhs rows] x [same]:  C -= P_I P_J^T.  The Gram blocks
+    // accumulate with the same sign (G = -Z Z^T, negated on output).
+    auto update = [&](int ks_, int I, int J) {
+        const double* PI = pblock_at(ks_, I);
+        const double* PJ = pblock_at(ks_, J);
+        double* Cb;
+        int ldc = BLD;
+        if (J >= nb1) {
+            Cb = G + ((I - nb1) * BB) * LDG + (J - nb1) * BB;
+            ldc = LDG;
+        } else if (I < nb1) {
+            Cb = Wb + sfb_pair(wrap(ks_ + 1 + I), wrap(ks_ + 1 + J)) * BS;
+        } else {
+            Cb = RH + ((I - nb1) * nbr + wrap(ks_ + 1 + J)) * BS;
+        }
+        sf_d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Cb[(lq + 4 * r) * ldc + l15];
+        const double* Ap = PI + l15 * BLD + lq;
+        const double* Bp = PJ + l15 * BLD + lq;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[kk * 4], Bp[kk * 4], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cb[(lq + 4 * r) * ldc + l15] = acc[r];
+    };
+
+    // step 0: every row block of the initial window is solved against L_00
+    for (int I = wave; I < RB; I += nwaves) xsolve(pblock_at(0, I));
+    sfb_barrier();
+
     int ks = 0;  // kb % nbr
     for (int kb = 0; kb < nblk; ++kb, ks = wrap(ks + 1)) {
-        auto pblock = [&](int I) -> double* {  // row block I below the diagonal block, column kb
-            return I < nb1 ? Wb + sfb_pair(wrap(ks + 1 + I), ks) * BS : RH + ((I - nb1) * nbr + ks) * BS;
-        };
-        // X = P L_kk^-T in place, on the matrix cores (B operand = rows of F = L_kk^-1)
-        auto xsolve = [&](double* P) {
-            sf_d4 acc = {0.0, 0.0, 0.0, 0.0};
-            const double* Ap = P + l15 * BLD + lq;
-            const double* Bp = Fb + l15 * BLD + lq;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[kk * 4], Bp[kk * 4], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) P[(lq + 4 * r) * BLD + l15] = acc[r];
-        };
-        // Block (I, J), I >= J, of [band rows below ; rhs rows] x [same]:  C -= P_I P_J^T
-        // (Gram blocks: G += Z_I Z_J^T)
-        auto update = [&](int I, int J) {
-            const double* PI = pblock(I);
-            const double* PJ = pblock(J);
-            double* Cb;
-            int ldc = BLD;
-            const bool gram = J >= nb1;
-            if (gram) {
-                Cb = G + ((I - nb1) * BB) * LDG + (J - nb1) * BB;
-                ldc = LDG;
-            } else if (I < nb1) {
-                Cb = Wb + sfb_pair(wrap(ks + 1 + I), wrap(ks + 1 + J)) * BS;
-            } else {
-                Cb = RH + ((I - nb1) * nbr + wrap(ks + 1 + J)) * BS;
-            }
-            sf_d4 acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = Cb[(lq + 4 * r) * ldc + l15];
-            const double* Ap = PI + l15 * BLD + lq;
-            const double* Bp = PJ + l15 * BLD + lq;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                double av = Ap[kk * 4];
-                if (!gram) av = -av;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bp[kk * 4], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cb[(lq + 4 * r) * ldc + l15] = acc[r];
-        };
-
-        // ---- S1: the prefetched block row kb-1+nbr lands in the slots retired by column kb-1, while
-        //      the row blocks that are already in the window are solved against L_kk
+        // ---- X: the prefetched block row kb-1+nbr lands in the slots retired by column kb-1; the wave
+        //      that owns the update of that row solves its block of column kb as soon as the four waves
+        //      holding it have stored it (LDS counter, no workgroup barrier); every wave then applies
+        //      block column kb+1 of the trailing update (J = 0), which the next diagonal block and the
+        //      next solve depend on.
         if (kb > 0) {
             const int rs = ks == 0 ? nbr - 1 : ks - 1;
             if (wave >= 4) {
@@ -259,6 +273,10 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
                     if (blk < nbr)
                         Wb[sfb_pair(rs, wrap(rs + 1 + blk)) * BS + pr * BLD + pc] = code == 1 ? pf[q] : code == 2 ? 1.0 : 0.0;
                 }
+                if (wave < 8) {  // group 0 holds block 0 = (new row, column kb) in its first register
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add((int*)&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             } else if (wave >= 1) {
 #pragma unroll
                 for (int q = 0; q < SFB_PF; ++q) {
@@ -268,30 +286,29 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
                 }
             }
         }
-        // all row blocks except the newest band row (index nb1-1, being written right now when kb > 0)
-        for (int I = wave; I < RB; I += nwaves)
-            if (I != nb1 - 1 || kb == 0) xsolve(pblock(I));
-        sfb_barrier();
-        SFB_TICK(0)
-
-        // ---- S2: the newest row block is solved by the wave that owns its update; then block column
-        //      kb+1 of the trailing update (J = 0): the next diagonal block and the next solve need it
         for (int I = wave; I < RB; I += nwaves) {
-            if (I == nb1 - 1 && kb > 0) xsolve(pblock(I));
-            update(I, 0);
+            if (I == nb1 - 1 && kb > 0) {
+                spin_until(1, 4 * kb);
+                xsolve(pblock_at(ks, I));
+            }
+            update(ks, I, 0);
         }
         sfb_barrier();
-        SFB_TICK(1)
 
-        // ---- S3: wave 0 -> next diagonal block; the others -> HBM prefetch, rest of the update, log
+        // ---- S: wave 0 -> next diagonal block and its inverse; the others -> HBM prefetch, rest of the
+        //      trailing update, log(pivot).  Whoever is done waits for the factor (LDS flag) and solves
+        //      its share of the row blocks of column kb+1 -- they were finished by phase X.
         if (wave == 0) {
-            if (kb + 1 < nblk) potrf16(kb + 1, wrap(ks + 1));
-            SFB_TICK(4)
+            if (kb + 1 < nblk) {
+                potrf16(kb + 1, wrap(ks + 1));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) sync[0] = kb + 1;
+            }
         } else {
             if (kb + 1 < nblk) {
                 const int gb = kb + nbr;
                 // straight-line code: all loads are issued back to back and nothing here reads their
-                // results (pfcode says at S1 whether a slot takes the loaded value, 1.0 or 0.0)
+                // results (pfcode says in phase X whether a slot takes the loaded value, 1.0 or 0.0)
                 pfcode = 0;
                 if (wave >= 4) {
                     const int i = gb * BB + pr;
@@ -317,23 +334,30 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
                     }
                 }
             }
-            SFB_TICK(2)
             // pairs (I, J), 1 <= J <= I < RB, in triangular order; wave w takes every (nwaves-1)-th
-            int Ip = 0, Jp = wave - 1;
+            // (the waves that share wave 0's SIMD -- every fourth one -- stay out of the way of the
+            // factorisation, which is the critical path of this phase)
+            const int nworkers = nwaves - (nwaves >> 2);
+            int Ip = 0, Jp = (wave & 3) ? wave - 1 - (wave >> 2) : 0x7fff;
             for (;;) {
                 while (Jp > Ip) {
                     Jp -= Ip + 1;
                     ++Ip;
+                    if (Ip > RB - 2) break;
                 }
                 if (Ip > RB - 2) break;
-                update(Ip + 1, Jp + 1);
-                Jp += nwaves - 1;
+                update(ks, Ip + 1, Jp + 1);
+                Jp += nworkers;
             }
-            SFB_TICK(4)
             if (wave == 1 && lane < BB) ld_acc += log(pv[(kb & 1) * BB + lane]);
         }
+        if (kb + 1 < nblk) {
+            spin_until(0, kb + 1);
+            const int ksn = wrap(ks + 1);
+            for (int I = wave; I < RB; I += nwaves)
+                if (I != nb1 - 1) xsolve(pblock_at(ksn, I));  // the newest row arrives in phase X
+        }
         sfb_barrier();
-        SFB_TICK(3)
     }
 
     // ---- outputs
@@ -346,15 +370,9 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
         if (bad && a.info && a.info[b] == 0) a.info[b] = bad;
     }
     double* out = a.gram + (int64_t)b * a.nrhs * a.nrhs;
-    if (a.dbg & 256) {
-        if ((tid == 0 || tid == 64 || tid == 256 || tid == 960) && b == 0)
-            printf("tid %d prefetch-issue %lld ", tid, tacc[2] / nblk),
-            printf("band_forms cycles/step: S1 %lld S2 %lld S3(wave0 potrf %lld, wait %lld) steps %d\n",
-                   tacc[0] / nblk, tacc[1] / nblk, tacc[4] / nblk, tacc[3] / nblk, nblk);
-    }
     for (int e = tid; e < a.nrhs * a.nrhs; e += nthreads) {
         const int r = e / a.nrhs, c = e - r * a.nrhs;
-        out[e] = (c <= r) ? G[r * LDG + c] : G[c * LDG + r];
+        out[e] = -((c <= r) ? G[r * LDG + c] : G[c * LDG + r]);
     }
 }
 
@@ -408,7 +426,7 @@ __global__ __launch_bounds__(64) void k_woodbury(const double* __restrict__ gram
 // ------------------------------------------------------------------------------------ launchers
 static size_t band_lds_bytes(int nbr, int nrb) {
     const size_t nr = (size_t)nrb * BB;
-    return sizeof(double) * ((size_t)nbr * (nbr + 1) / 2 * BS + (size_t)nrb * nbr * BS + BS + nr * (nr + 1) + 3 * BB);
+    return sizeof(double) * ((size_t)nbr * (nbr + 1) / 2 * BS + (size_t)nrb * nbr * BS + BS + nr * (nr + 1) + 4 * BB);
 }
 
 static int band_nbr(int halfwidth) {  // window rows >= W + 16, and at least three blocks (see S2)
@@ -457,8 +475,6 @@ int sf_launch_band_forms(const double* band, int n, int halfwidth, int ldb, int6
     a.logdet = logdet;
     a.gram = gram;
     a.info = info;
-    static const int dbg = getenv("SF_BAND_DBG") ? atoi(getenv("SF_BAND_DBG")) : 0;
-    a.dbg = dbg;
     static bool attr_set = false;
     if (!attr_set) {
         SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -302,18 +302,32 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
 // order of additions are those of k_fill_band.  A thread on the last stored diagonal also probes the
 // first diagonal outside the storage: a non-zero there means the caller's half-width is too small
 // for this walker -> info = SF_INFO_BANDWIDTH (the result would silently drop covariance otherwise).
+// The element formulas are those of sf_matern_elem / sf_local_elem with the per-walker divisions
+// hoisted into reciprocals and cos(pi x) evaluated as cospi(x) (differences ~1e-16 relative, far inside
+// the 1e-10 covariance tolerance; the dense fill keeps the reference's exact operation order).
 __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __restrict__ band, int ws, int ldb,
                                                    int64_t sband, int* __restrict__ info) {
     // per-walker constants once per block: exp() of the hyper-parameters (spectrum_model.py:343-357)
-    __shared__ double s_glob[2];
-    __shared__ double s_loc[SF_MAX_LOCAL][3];
+    __shared__ double s_glob[4];                 // amp, r0, 1/r0, sqrt(3)/ls
+    __shared__ double s_loc[SF_MAX_LOCAL][6];    // mu, amp, r0, 1/r0, -0.5/sigma^2, c/mu
     const int b = blockIdx.y;
     const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
-    if (threadIdx.x < 2 && a.has_global) s_glob[threadIdx.x] = exp(P[a.off_global + threadIdx.x]);
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * a.n_local) {
-        const int q = threadIdx.x - 64, k = q / 3, f = q - 3 * k;
-        const double v = P[a.off_local + q];
-        s_loc[k][f] = f == 0 ? v : exp(v);
+    if (threadIdx.x == 0 && a.has_global) {
+        const double amp = exp(P[a.off_global]), ls = exp(P[a.off_global + 1]);
+        s_glob[0] = amp;
+        s_glob[1] = 6 * ls;
+        s_glob[2] = 1.0 / (6 * ls);
+        s_glob[3] = 1.7320508075688772 / ls;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + a.n_local) {
+        const int k = threadIdx.x - 64;
+        const double sig = exp(P[a.off_local + 3 * k + 2]);
+        s_loc[k][0] = P[a.off_local + 3 * k];
+        s_loc[k][1] = exp(P[a.off_local + 3 * k + 1]);
+        s_loc[k][2] = 4 * sig;
+        s_loc[k][3] = 1.0 / (4 * sig);
+        s_loc[k][4] = -0.5 / (sig * sig);
+        s_loc[k][5] = SF_C_KMS / s_loc[k][0];
     }
     __syncthreads();
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -329,20 +343,22 @@ __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __res
             const double w_col = a.wave[col];
             double acc = 0.0;
             if (a.has_global) {
-                const double g = sf_matern_elem(w_row, w_col, s_glob[0], s_glob[1], 6 * s_glob[1]);
-                acc = g;
-                any = any || g != 0.0;
-            }
-            if (a.n_local > 0) {
-                double loc = 0.0;
-                for (int k = 0; k < a.n_local; ++k) {
-                    const double mu = s_loc[k][0], amp = s_loc[k][1], sig = s_loc[k][2];
-                    const double l = sf_local_elem(sf_local_metric(w_row, mu), sf_local_metric(w_col, mu), amp,
-                                                   sig, 4 * sig);
-                    loc = loc + l;
-                    any = any || l != 0.0;
+                const double r = SF_C_KMS / 2 * fabs((w_col - w_row) / (w_col + w_row));
+                if (r <= s_glob[1]) {
+                    const double t = s_glob[3] * r;
+                    acc = (0.5 + 0.5 * cospi(r * s_glob[2])) * s_glob[0] * (1 + t) * exp(-t);
+                    any = true;
                 }
-                acc = acc + loc;
+            }
+            for (int k = 0; k < a.n_local; ++k) {
+                const double mu = s_loc[k][0], cm = s_loc[k][5];
+                const double d_row = cm * fabs(w_row - mu), d_col = cm * fabs(w_col - mu);
+                const double r_tap = fmax(d_row, d_col);
+                if (r_tap <= s_loc[k][2]) {
+                    acc += (0.5 + 0.5 * cospi(r_tap * s_loc[k][3])) * s_loc[k][1] *
+                           exp((d_col * d_col + d_row * d_row) * s_loc[k][4]);
+                    any = true;
+                }
             }
             return acc;
         };

@@ -45,7 +45,7 @@ class SpectrumModel:
     _LOCAL_PARAMS = ["mu", "log_amp", "log_sigma"]
 
     def __init__(self, emulator, data, grid_params, max_deque_len=100, norm=False, name="SpectrumModel",
-                 device=None, **params):
+                 device=None, solver="dense", **params):
         if isinstance(emulator, str):
             emulator = Emulator.load(emulator)
         if isinstance(data, str):
@@ -57,6 +57,12 @@ class SpectrumModel:
         self.data_name = data.name
         self.data = data[0]
         self._device_index = device
+        #: "dense" = the reference's algorithm (batched N x N Cholesky); "auto" = band + rank-m Woodbury
+        #: solve whenever the covariance support fits the device window (same value to rounding, ~20x
+        #: faster at N = 4096), dense otherwise; "banded" = structured solve only (info -4 if too wide)
+        if solver not in ("dense", "banded", "auto"):
+            raise ValueError("solver must be 'dense', 'banded' or 'auto'")
+        self.solver = solver
 
         dv = calculate_dv(self.data.wave)
         self.min_dv_wave = create_log_lam_grid(dv, self.emulator.wl.min(), self.emulator.wl.max())["wl"]
@@ -397,7 +403,7 @@ class SpectrumModel:
         if not np.isfinite(prior_lp):
             return -np.inf
         dev, md, rows = self._pack()
-        out = dev.loglike(md, rows, want_resid=True)
+        out = dev.loglike(md, rows, want_resid=True, solver=self.solver)
         self.last_info = out["info"]
         self._raise_for_info(out["info"][0])
         self._log_scale = float(out["log_scale"][0])
@@ -427,7 +433,7 @@ class SpectrumModel:
         info = np.zeros(P.shape[0], dtype=np.int32)
         if finite.any():
             dev, md, rows = self._pack(P[finite])
-            out = dev.loglike(md, rows)
+            out = dev.loglike(md, rows, solver=self.solver)
             lnl[finite] = out["lnl"] + prior_lp[finite]
             info[finite] = out["info"]
         self.last_info = info

@@ -96,6 +96,50 @@ def test_emcee_style_loop_and_batch_agree():
     assert ll[1] == -np.inf and ll[2] == -np.inf and info[2] == -1 and np.isfinite(ll[0])
 
 
+def test_structured_solver_option_matches_the_dense_model():
+    """solver="auto" (band + rank-m Woodbury, dense fallback) is a drop-in for the default dense solve:
+    same values from the reference's driver loop, the batched front-end, frozen caches and the sampler."""
+    import scipy.stats as st
+
+    g = load_golden("model_large.npz")
+    o = synth.make_order(N=1024)
+    dense, auto = build(o), build(o)
+    auto.solver = "auto"
+    priors = {"vsini": st.uniform(0, 500), "T": st.norm(6050, 100)}
+    P = g["n1024_batch_P"][:6]
+    a = auto.log_likelihood_batch(P, priors)
+    np.testing.assert_allclose(a, dense.log_likelihood_batch(P, priors), rtol=1e-11)
+    for b in range(6):
+        prior = sum(pr.logpdf(P[b][auto.labels.index(k)]) for k, pr in priors.items())
+        assert close(a[b] - prior, g["n1024_batch_lnl"][b])
+    auto.set_param_vector(P[0])
+    assert close(auto.log_likelihood(), g["n1024_batch_lnl"][0])
+    np.testing.assert_allclose(auto.residuals[-1], dense_resid(dense, P[0]), rtol=0, atol=1e-12)
+    # frozen covariance hyper-parameters: the cached values are the ones the band is built from
+    auto.freeze("global_cov")
+    dense.set_param_vector(P[0])
+    dense.freeze("global_cov")
+    v0, d0 = auto.log_likelihood(), dense.log_likelihood()
+    auto["global_cov:log_amp"] = -7.0
+    dense["global_cov:log_amp"] = -7.0
+    assert auto.log_likelihood() == v0 and dense.log_likelihood() == d0
+    assert close(v0, d0)
+    # a length scale too wide for the device window silently takes the dense route
+    auto.thaw("global_cov")
+    dense.thaw("global_cov")
+    auto["global_cov:log_ls"] = dense["global_cov:log_ls"] = float(np.log(300.0))
+    assert close(auto.log_likelihood(), dense.log_likelihood())
+    with pytest.raises(ValueError):
+        build(o).__class__(auto.emulator, Spectrum(o["wave"], o["flux"], sigmas=o["sigma"]), [6050.0, 4.2, -0.3],
+                           solver="fast")
+
+
+def dense_resid(model, p):
+    model.set_param_vector(p)
+    model.log_likelihood()
+    return model.residuals[-1]
+
+
 def test_scalar_path_raises_like_the_reference():
     o = synth.make_order(N=256, m=4, seed=5)
     m = build(o)
