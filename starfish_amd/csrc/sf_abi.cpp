@@ -811,7 +811,7 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
 
 // ------------------------------------------------------------------- structure-exploiting solver
 struct BandWork {
-    double *band, *gram, *logdet_band;
+    double *band, *gram, *logdet_band, *twist;
     int ldb;
     size_t bytes;
 };
@@ -824,6 +824,7 @@ static BandWork carve_band(const sf_ctx* c, const sf_model_desc* mdl, int B, int
     w.band = k.take<double>((size_t)B * c->npad * w.ldb);
     w.gram = k.take<double>((size_t)B * (c->m + 1) * (c->m + 1));
     w.logdet_band = k.take<double>((size_t)B);
+    w.twist = k.take<double>(sf_band_twisted_work_doubles(halfwidth, c->m + 1, B));
     w.bytes = sf_align_up(k.off, 256);
     return w;
 }
@@ -882,9 +883,14 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
     }
     {
         ProfScope ps(s, PS_POTRF);
-        rc = sf_launch_band_forms(bw.band, (c->n + 15) / 16 * 16, halfwidth, bw.ldb, sband, B, w.resid, c->npad,
-                                  w.Y, c->m + 1, c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band, bw.gram,
-                                  w.info_c, s);
+        const int n16 = (c->n + 15) / 16 * 16;
+        if (sf_band_twisted_applicable(n16, halfwidth, B))
+            rc = sf_launch_band_forms_twisted(bw.band, n16, halfwidth, bw.ldb, sband, B, w.resid, c->npad, w.Y,
+                                              c->m + 1, c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band,
+                                              bw.gram, w.info_c, bw.twist, s);
+        else
+            rc = sf_launch_band_forms(bw.band, n16, halfwidth, bw.ldb, sband, B, w.resid, c->npad, w.Y, c->m + 1,
+                                      c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band, bw.gram, w.info_c, s);
         if (rc) return rc;
     }
     {

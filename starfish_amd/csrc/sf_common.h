@@ -87,6 +87,14 @@ int sf_launch_local_cov(const double* wave, int n, double amp, double mu, double
 int sf_band_max_halfwidth(int nrhs);
 int sf_launch_band_forms(const double* band, int n, int halfwidth, int ldb, int64_t sband, int batch,
                          const double* rhs0, int64_t srhs0, const double* rhs, int nrhs, int ldr,
-                         int64_t srhs, double* logdet, double* gram, int* info, hipStream_t s);
+                         int64_t srhs, double* logdet, double* gram, int* info, hipStream_t s,
+                         const double* logdet_add = nullptr, const double* gram_add = nullptr, int info_off = 0);
+// two half sweeps + separator (halves the sequential chain when 2*batch workgroups fit the chip)
+size_t sf_band_twisted_work_doubles(int halfwidth, int nrhs, int batch);
+bool sf_band_twisted_applicable(int n, int halfwidth, int batch);
+int sf_launch_band_forms_twisted(const double* band, int n, int halfwidth, int ldb, int64_t sband, int batch,
+                                 const double* rhs0, int64_t srhs0, const double* rhs, int nrhs, int ldr,
+                                 int64_t srhs, double* logdet, double* gram, int* info, double* work,
+                                 hipStream_t s);
 int sf_launch_woodbury(const double* gram, int nrhs, int batch, const double* logdet_band, double* logdet,
                        double* sqmah, int* info, hipStream_t s);
