@@ -420,7 +420,19 @@ extern "C" sf_ctx* sf_ctx_create(const sf_order_desc* d, int device, int* err) {
     {
         std::vector<double> band;
         truncated_inverse_band(d->nf, Lf, Uf, rdiag, band);
-        TRY(c->inv_band.upload(band.data(), sizeof(double) * band.size()));
+        // 16 x 16 coefficient blocks for the MFMA band product (k_spline_apply): output block ib uses the
+        // input blocks ib-4 .. ib+4
+        const int nfb = d->nf / 16, nkb = 2 * (SF_IW / 16) + 1, n = d->nf;
+        std::vector<double> tblk((size_t)nfb * nkb * 256, 0.0);
+        for (int ib = 0; ib < nfb; ++ib)
+            for (int kb = 0; kb < nkb; ++kb)
+                for (int r = 0; r < 16; ++r)
+                    for (int cc = 0; cc < 16; ++cc) {
+                        const int i = ib * 16 + r, k = (ib - SF_IW / 16 + kb) * 16 + cc;
+                        if (k < 0 || k >= n || k - i > SF_IW || i - k > SF_IW) continue;
+                        tblk[(((size_t)ib * nkb + kb) * 16 + r) * 16 + cc] = band[(size_t)(k - i + SF_IW) * n + i];
+                    }
+        TRY(c->inv_band.upload(tblk.data(), sizeof(double) * tblk.size()));
     }
     make_twiddles(d->nf, tw);
     TRY(c->tw.upload(tw.data(), sizeof(double) * tw.size()));
@@ -505,7 +517,7 @@ struct Carve {
     }
 };
 struct Work {
-    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *ybro, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf;
+    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *ybro, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf, *mult;
     double2* fft;
     int *info_e, *info_c;
     unsigned char* tilemap;
@@ -525,7 +537,8 @@ static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, siz
     w.info_c = k.take<int>(b);
     w.coef = mdl->has_vsini ? k.take<double>(b * c->nf * c->rows) : nullptr;
     w.ybro = mdl->has_vsini ? k.take<double>(b * c->nf * c->rows) : nullptr;  // broadened rows before the fit
-    const size_t fb = mdl->has_vsini ? sf_fft_scratch_bytes(B * c->rows, c->nf) : 0;
+    w.mult = mdl->has_vsini ? k.take<double>(b * (c->nf / 2 + 1)) : nullptr;  // broadening kernel per walker
+    const size_t fb = mdl->has_vsini ? sf_fft_half_scratch_bytes(B * c->rows, c->nf) : 0;
     w.fft = fb ? k.take<double2>(fb / sizeof(double2)) : nullptr;
     w.Xraw = k.take<double>(b * c->m * c->npad);
     w.fraw = k.take<double>(b * c->npad);
@@ -596,6 +609,7 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
         a.orow = 1;
         a.oelem = c->rows;
         a.gscratch = w.fft;
+        a.mult = w.mult;
         a.info = w.info_e;
         rc = sf_launch_broaden(a, s);
         if (rc) return rc;
@@ -977,6 +991,7 @@ static int broaden_free(const double* d_flux, int rows, int nf, double dv, int k
     a.orow = nf;
     a.oelem = 1;
     a.gscratch = scratch;
+    a.mult = nullptr;
     a.info = nullptr;
     return sf_launch_broaden(a, s);
 }

@@ -19,9 +19,12 @@ struct sf_broaden_args {
     double* out;
     int64_t ob, orow, oelem;  // strides of the output: item, row, element
     double2* gscratch;     // B*rows*nf complex when nf does not fit the LDS
+    double* mult;          // optional B x (nf/2+1) scratch (context path): per-walker multiplier table ->
+                           // half-size FFT kernel
     int* info;
 };
 size_t sf_fft_scratch_bytes(int rows_total, int nf);
+size_t sf_fft_half_scratch_bytes(int rows_total, int nf);
 int sf_launch_broaden(const sf_broaden_args& a, hipStream_t s);
 int sf_launch_rfft_rows(const double* in, int rows, int nf, const double2* tw, double2* spec,
                         double2* gscratch, hipStream_t s);

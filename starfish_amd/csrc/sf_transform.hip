@@ -9,6 +9,7 @@
 //   k_emulator       GP conditional of the PCA weights      Starfish/emulator/emulator.py:330-394
 #include "sf_common.h"
 #include "sf_transform.h"
+typedef double sf_d4x __attribute__((ext_vector_type(4)));
 
 // --------------------------------------------------------------------------------------- FFT
 // In-place radix-2 decimation-in-time FFT on `buf` (LDS or global), input already bit-reversed.
@@ -17,11 +18,12 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-__device__ void sf_fft_inplace(double2* buf, int L, const double2* __restrict__ tw, bool inverse) {
+// `twmul`: the table holds exp(-2 pi i k / (twmul * L)) (a table made for a longer transform).
+__device__ void sf_fft_inplace(double2* buf, int L, const double2* __restrict__ tw, bool inverse, int twmul = 1) {
     const int tid = threadIdx.x, nth = blockDim.x;
     int ls = 0;  // log2(half-size)
     for (int s = 1; s < L; s <<= 1, ++ls) {
-        const int twstep = L / (2 * s);
+        const int twstep = L / (2 * s) * twmul;
         for (int idx = tid; idx < L / 2; idx += nth) {
             const int j = idx & (s - 1);
             const int i0 = ((idx >> ls) << (ls + 1)) + j;
@@ -140,6 +142,71 @@ __global__ __launch_bounds__(256) void k_broaden(const double* __restrict__ in,
     const double inv_n = 1.0 / nf;
     double* o = out + (int64_t)b * ob + (int64_t)row * orow;
     for (int j = tid; j < nf; j += 256) o[(int64_t)j * oelem] = buf[j].x * inv_n;
+}
+
+// Hot-path variant (precomputed half spectra): the kernel multiplier depends on the walker only, so it is
+// tabulated once per walker (k_kernel_mult) instead of once per row, and the real inverse transform runs
+// as a HALF-size complex FFT:  Z_k = (X_k + conj X_{L-k}) + i e^{+2 pi i k/nf} (X_k - conj X_{L-k}),
+// L = nf/2;  z = IDFT_L(Z)  =>  x_{2m} = Re z_m, x_{2m+1} = Im z_m.  64 KiB of LDS at nf = 8192.
+__global__ __launch_bounds__(256) void k_kernel_mult(double* __restrict__ mult, int nh1, double val, int kind,
+                                                     const double* __restrict__ params, int pstride, int poff,
+                                                     double scalar_param, int* __restrict__ info) {
+    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    double param = scalar_param;
+    if (params) param = params[(int64_t)b * pstride + poff];
+    if (kind == 1 && !(param > 0.0)) {  // transforms.py:121-122
+        if (k == 0 && info) atomicCAS(&info[b], 0, SF_INFO_BAD_VSINI);
+        return;
+    }
+    if (k >= nh1) return;
+    double m = 1.0;
+    if (kind == 1) m = sf_rot_mult(k, val, param);
+    else if (kind == 2) m = sf_inst_mult(k, val, param);
+    mult[(int64_t)b * nh1 + k] = m;
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_broaden_half(const double2* __restrict__ spec,
+                                                      const double* __restrict__ mult, int rows, int nf,
+                                                      const double2* __restrict__ tw, int kind,
+                                                      const double* __restrict__ params, int pstride, int poff,
+                                                      double scalar_param, double* __restrict__ out, int64_t ob,
+                                                      int64_t orow, int64_t oelem, double2* __restrict__ gscratch) {
+    extern __shared__ __attribute__((aligned(16))) double2 lbuf[];
+    const int row = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int L = nf / 2;
+    double2* buf = USE_LDS ? lbuf : gscratch + ((int64_t)b * rows + row) * nf;
+    double param = scalar_param;
+    if (params) param = params[(int64_t)b * pstride + poff];
+    if (kind == 1 && !(param > 0.0)) return;  // flagged by k_kernel_mult
+    int bits = 0;
+    while ((1 << bits) < L) ++bits;
+    const double2* X = spec + (int64_t)row * (L + 1);
+    const double* mb = mult + (int64_t)b * (L + 1);
+    for (int k = tid; k < L; k += 256) {
+        double2 a = X[k], c = X[L - k];
+        const double ma = mb[k], mc = mb[L - k];
+        a.x *= ma;
+        a.y *= ma;
+        c.x *= mc;
+        c.y *= mc;
+        if (k == 0) a.y = 0.0, c.y = 0.0;  // c2r ignores the imaginary part of DC / Nyquist
+        // conj(X_{L-k}) = (c.x, -c.y)
+        const double2 E = make_double2(a.x + c.x, a.y - c.y);
+        const double2 D = make_double2(a.x - c.x, a.y + c.y);
+        const double2 w = tw[k];  // exp(-2 pi i k / nf); we need its conjugate
+        const double2 O = make_double2(w.x * D.x + w.y * D.y, w.x * D.y - w.y * D.x);
+        buf[sf_bitrev((unsigned)k, bits)] = make_double2(E.x - O.y, E.y + O.x);
+    }
+    __syncthreads();
+    sf_fft_inplace(buf, L, tw, true, 2);
+    const double inv_n = 1.0 / nf;
+    double* o = out + (int64_t)b * ob + (int64_t)row * orow;
+    for (int m = tid; m < L; m += 256) {
+        const double2 z = buf[m];
+        o[(int64_t)(2 * m) * oelem] = z.x * inv_n;
+        o[(int64_t)(2 * m + 1) * oelem] = z.y * inv_n;
+    }
 }
 
 // Forward half spectrum of static rows (context creation): spec[row][k], k <= nf/2.
@@ -266,36 +333,76 @@ __global__ __launch_bounds__(64) void k_spline_solve(double* __restrict__ data, 
 // Fully parallel variant for the per-walker path: the collocation matrix of the fixed log-lambda grid is
 // well conditioned (cond ~ 15) and its inverse decays like 0.43^|i-j|, so c_i = sum_{|d| <= SF_IW}
 // Ainv[i][i+d] y_{i+d} with the band precomputed at context creation (truncation < 1e-23 relative).
-// y / c are [B][n][rows]; band is [(2 SF_IW + 1)][n] (offset-major, coalesced over i).
-template <int RC>
+// That is a block-banded matrix product and runs on v_mfma_f64_16x16x4_f64:
+//   C[16 i's][rows] = sum over the 9 input blocks kb of  T[ib][kb] (16 x 16)  x  Y[16 k's][rows]
+// One wave owns one block of 16 outputs and keeps its 9 T blocks in registers (36 A fragments) while it
+// loops over a chunk of walkers, so the 9.4 MB table is read B/chunk times, not B times; the B operand
+// (lane (k, r) <- y[b][k][r], rows contiguous) and the result are addressed straight in HBM/L2: no LDS.
+// The walker loop is software pipelined: the fragments of walker b+1 are in flight while the matrix
+// core works on walker b.
+// y / c are [B][n][rows]; tblk is [n/16][SF_IBLK][16][16] (zero outside the band / the matrix).
+#define SF_IBLK (2 * (SF_IW / 16) + 1)
+template <int NCB>
 __global__ __launch_bounds__(256) void k_spline_apply(const double* __restrict__ y, double* __restrict__ c,
-                                                      int rows, int n, const double* __restrict__ band) {
-    extern __shared__ double ywin[];  // (256 + 2 SF_IW) x rows
-    const int i0 = blockIdx.x * 256, b = blockIdx.y, tid = threadIdx.x;
-    const double* yb = y + (int64_t)b * n * rows;
-    const int nwin = 256 + 2 * SF_IW;
-    for (int e = tid; e < nwin * rows; e += 256) {
-        const int j = i0 - SF_IW + e / rows;
-        ywin[e] = (j >= 0 && j < n) ? yb[(int64_t)j * rows + e % rows] : 0.0;
-    }
-    __syncthreads();
-    const int i = i0 + tid;
-    if (i >= n) return;
-    double* cb = c + ((int64_t)b * n + i) * rows;
-    for (int r0 = 0; r0 < rows; r0 += RC) {
-        double acc[RC];
+                                                      int rows, int n, const double* __restrict__ tblk, int B,
+                                                      int wchunk) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+    const int ib = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ib * 16 >= n) return;
+    double a[SF_IBLK][4];
 #pragma unroll
-        for (int q = 0; q < RC; ++q) acc[q] = 0.0;
-        for (int d = 0; d <= 2 * SF_IW; ++d) {
-            const double a = band[(int64_t)d * n + i];
-            const double* yr = &ywin[(tid + d) * rows + r0];
+    for (int kb = 0; kb < SF_IBLK; ++kb)
 #pragma unroll
-            for (int q = 0; q < RC; ++q)
-                if (r0 + q < rows) acc[q] += a * yr[q];
+        for (int kk = 0; kk < 4; ++kk)
+            a[kb][kk] = tblk[(((int64_t)ib * SF_IBLK + kb) * 16 + l15) * 16 + kk * 4 + lq];
+    const int kbase = (ib - SF_IW / 16) * 16 + lq;
+    const int b0 = blockIdx.y * wchunk, b1 = min(B, b0 + wchunk);
+    double bA[SF_IBLK][4][NCB], bB[SF_IBLK][4][NCB];
+    auto fetch = [&](int b, double (&dst)[SF_IBLK][4][NCB]) {
+        const double* yb = y + (int64_t)b * n * rows;
+#pragma unroll
+        for (int kb = 0; kb < SF_IBLK; ++kb)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                int k = kbase + kb * 16 + kk * 4;  // blocks outside the matrix carry zero coefficients
+                k = k < 0 ? 0 : (k >= n ? n - 1 : k);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const int r = cb * 16 + l15;
+                    dst[kb][kk][cb] = yb[k * rows + (r < rows ? r : 0)];  // columns >= rows: never stored
+                }
+            }
+    };
+    auto compute = [&](int b, const double (&bv)[SF_IBLK][4][NCB]) {
+        sf_d4x acc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = (sf_d4x){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kb = 0; kb < SF_IBLK; ++kb)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb][kk], bv[kb][kk][cb], acc[cb], 0, 0, 0);
+        double* cb_ = c + (int64_t)b * n * rows;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int i = ib * 16 + lq + 4 * r4;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int r = cb * 16 + l15;
+                if (r < rows && i < n) cb_[(int64_t)i * rows + r] = acc[cb][r4];
+            }
         }
-#pragma unroll
-        for (int q = 0; q < RC; ++q)
-            if (r0 + q < rows) cb[r0 + q] = acc[q];
+    };
+    if (b0 < b1) fetch(b0, bA);
+    for (int b = b0; b < b1; b += 2) {  // ping-pong: the fragments of the next walker are in flight
+        if (b + 1 < b1) fetch(b + 1, bB);
+        compute(b, bA);
+        if (b + 1 < b1) {
+            if (b + 2 < b1) fetch(b + 2, bA);
+            compute(b + 1, bB);
+        }
     }
 }
 
@@ -648,8 +755,11 @@ __global__ void k_finish(int B, const double* __restrict__ logdet, const double*
 // ------------------------------------------------------------------------------------ launchers
 static const size_t kLdsFftMax = 8192;  // complex points that fit the 160 KiB LDS (128 KiB)
 
-size_t sf_fft_scratch_bytes(int rows_total, int nf) {
+size_t sf_fft_scratch_bytes(int rows_total, int nf) {  // full-size transform (free functions, set-up)
     return (size_t)nf > kLdsFftMax ? sizeof(double2) * (size_t)rows_total * nf : 0;
+}
+size_t sf_fft_half_scratch_bytes(int rows_total, int nf) {  // half-size transform of the hot path
+    return (size_t)(nf / 2) > kLdsFftMax ? sizeof(double2) * (size_t)rows_total * nf : 0;
 }
 
 template <bool FWD>
@@ -682,11 +792,42 @@ static int launch_broaden_t(const sf_broaden_args& a, hipStream_t s) {
     return SF_OK;
 }
 
+static int launch_broaden_half(const sf_broaden_args& a, hipStream_t s) {
+    const int nh1 = a.nf / 2 + 1;
+    const double val = 1.0 / (a.nf * a.dv);  // numpy.fft.rfftfreq
+    hipLaunchKernelGGL(k_kernel_mult, dim3((nh1 + 255) / 256, a.B), dim3(256), 0, s, a.mult, nh1, val, a.kind,
+                       a.params, a.pstride, a.poff, a.scalar_param, a.info);
+    SF_LAUNCH_CHECK();
+    const bool lds = (size_t)(a.nf / 2) <= kLdsFftMax;
+    dim3 grid(a.rows, a.B);
+    if (lds) {
+        static bool set = false;
+        if (!set) {
+            SF_HIP(hipFuncSetAttribute((const void*)k_broaden_half<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            set = true;
+        }
+        hipLaunchKernelGGL(k_broaden_half<true>, grid, dim3(256), sizeof(double2) * (size_t)(a.nf / 2), s, a.spec,
+                           a.mult, a.rows, a.nf, a.tw, a.kind, a.params, a.pstride, a.poff, a.scalar_param, a.out,
+                           a.ob, a.orow, a.oelem, (double2*)nullptr);
+    } else {
+        if (!a.gscratch) {
+            sf_set_error("broaden: nf=%d needs a global FFT scratch buffer", a.nf);
+            return SF_ENOMEM;
+        }
+        hipLaunchKernelGGL(k_broaden_half<false>, grid, dim3(256), 0, s, a.spec, a.mult, a.rows, a.nf, a.tw, a.kind,
+                           a.params, a.pstride, a.poff, a.scalar_param, a.out, a.ob, a.orow, a.oelem, a.gscratch);
+    }
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
 int sf_launch_broaden(const sf_broaden_args& a, hipStream_t s) {
-    if (a.nf < 2 || (a.nf & (a.nf - 1)) || a.nf > 65536) {
-        sf_set_error("broaden: nf=%d must be a power of two in [2, 65536]", a.nf);
+    if (a.nf < 4 || (a.nf & (a.nf - 1)) || a.nf > 65536) {
+        sf_set_error("broaden: nf=%d must be a power of two in [4, 65536]", a.nf);
         return SF_EINVAL;
     }
+    if (!a.in && a.mult) return launch_broaden_half(a, s);
     return a.in ? launch_broaden_t<true>(a, s) : launch_broaden_t<false>(a, s);
 }
 
@@ -719,19 +860,19 @@ int sf_launch_spline_solve(double* data, int B, int rows, int64_t bstride, int64
     return SF_OK;
 }
 
-int sf_launch_spline_apply(const double* y, double* c, int B, int rows, int n, const double* band, hipStream_t s) {
-    const size_t shm = sizeof(double) * (size_t)(256 + 2 * SF_IW) * rows;
-    if (shm > 150 * 1024) {
-        sf_set_error("spline_apply: too many rows (%d)", rows);
+int sf_launch_spline_apply(const double* y, double* c, int B, int rows, int n, const double* tblk, hipStream_t s) {
+    const int ncb = (rows + 15) / 16;
+    if (ncb > 2 || n % 16) {
+        sf_set_error("spline_apply: rows=%d n=%d not supported", rows, n);
         return SF_EINVAL;
     }
-    static bool set = false;
-    if (!set) {
-        SF_HIP(hipFuncSetAttribute((const void*)k_spline_apply<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-        set = true;
-    }
-    hipLaunchKernelGGL(k_spline_apply<10>, dim3((n + 255) / 256, B), dim3(256), shm, s, y, c, rows, n, band);
+    // enough waves to fill the chip (n/16 output blocks x walker chunks), long enough chunks to amortise
+    // the register-resident coefficient blocks
+    int wchunk = 32;
+    while (wchunk > 4 && (int64_t)(n / 16) * ((B + wchunk - 1) / wchunk) < 2048) wchunk >>= 1;
+    const dim3 grid((n / 16 + 3) / 4, (B + wchunk - 1) / wchunk);
+    if (ncb == 1) hipLaunchKernelGGL(k_spline_apply<1>, grid, dim3(256), 0, s, y, c, rows, n, tblk, B, wchunk);
+    else hipLaunchKernelGGL(k_spline_apply<2>, grid, dim3(256), 0, s, y, c, rows, n, tblk, B, wchunk);
     SF_LAUNCH_CHECK();
     return SF_OK;
 }
