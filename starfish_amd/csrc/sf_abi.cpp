@@ -287,6 +287,7 @@ struct sf_ctx {
     int device = 0;
     int n = 0, nf = 0, m = 0, P = 0, M = 0, npad = 0, lda = 0, mpad = 0, rows = 0;
     int monotonic = 1;
+    int loguniform = 0;  // wave_i = wave_0 e^(i delta) to the rounding of the grid
     double dv = 0.0, wave_max = 0.0;
     DevBuf wave, flux, sigma, knots, spec, tw, Lf, Uf, rdiag, coef_static, inv_band;
     DevBuf grid, variances, lengthscales, gmin, gmax, alpha, Linv;
@@ -396,6 +397,17 @@ extern "C" sf_ctx* sf_ctx_create(const sf_order_desc* d, int device, int* err) {
     for (int i = 0; i < d->n; ++i) {
         if (d->wave[i] > c->wave_max) c->wave_max = d->wave[i];
         if (i && !(d->wave[i] > d->wave[i - 1])) c->monotonic = 0;
+    }
+    if (c->monotonic && d->n > 2) {
+        // log-uniform grid?  (w_i - w_{i-1}) / (w_i + w_{i-1}) = tanh(delta/2) for every i, to the
+        // rounding of the wavelengths themselves (relative spread ~ ulp(w)/dw, e.g. 3e-11 at 5000 A, dv = 2)
+        double qmin = 1e300, qmax = 0.0;
+        for (int i = 1; i < d->n; ++i) {
+            const double q = (d->wave[i] - d->wave[i - 1]) / (d->wave[i] + d->wave[i - 1]);
+            qmin = q < qmin ? q : qmin;
+            qmax = q > qmax ? q : qmax;
+        }
+        c->loguniform = (qmax - qmin) <= 2e-10 * qmax;
     }
 #define TRY(x)              \
     do {                    \
@@ -697,6 +709,7 @@ static sf_fill_args fill_args(sf_ctx* c, const sf_model_desc* mdl, const double*
     f.off_global = 4;
     f.off_local = 6 + c->P + mdl->n_cheb;
     f.monotonic = c->monotonic;
+    f.loguniform = c->loguniform;
     f.tilemap = nullptr;
     f.nt128 = 0;
     return f;
@@ -825,7 +838,7 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
 
 // ------------------------------------------------------------------- structure-exploiting solver
 struct BandWork {
-    double *band, *gram, *logdet_band, *twist;
+    double *band, *gram, *logdet_band, *twist, *gtab;
     int ldb;
     size_t bytes;
 };
@@ -839,6 +852,7 @@ static BandWork carve_band(const sf_ctx* c, const sf_model_desc* mdl, int B, int
     w.gram = k.take<double>((size_t)B * (c->m + 1) * (c->m + 1));
     w.logdet_band = k.take<double>((size_t)B);
     w.twist = k.take<double>(sf_band_twisted_work_doubles(halfwidth, c->m + 1, B));
+    w.gtab = k.take<double>((size_t)B * (halfwidth + 2));
     w.bytes = sf_align_up(k.off, 256);
     return w;
 }
@@ -892,7 +906,7 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         f.lower_only = 1;
         f.add_jitter = 1;
         f.npad = (c->n + 15) / 16 * 16;
-        rc = sf_launch_band_fill(f, B, bw.band, halfwidth + 1, bw.ldb, sband, w.info_c, s);
+        rc = sf_launch_band_fill(f, B, bw.band, halfwidth + 1, bw.ldb, sband, w.info_c, bw.gtab, s);
         if (rc) return rc;
     }
     {

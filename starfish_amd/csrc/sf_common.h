@@ -72,13 +72,14 @@ struct sf_fill_args {
     int lower_only;        // 1: only tiles touching the lower triangle, identity padding written
     int add_jitter;        // 1: + SF_JITTER on the diagonal
     int monotonic;         // wave sorted ascending -> band culling allowed
+    int loguniform;        // wave_i = wave_0 e^(i delta) to rounding -> K_global depends on i-j only
     unsigned char* tilemap; // optional [B][nt128*nt128]: 1 = the 128x128 tile is materialised in C
     int nt128;
 };
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);
 // band storage of the structured part of C (sf_band.hip consumes it); a.npad = rows written (>= a.n)
 int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int ldb, int64_t sband, int* info,
-                        hipStream_t s);
+                        double* gtab, hipStream_t s);  // gtab: B x (ws+1) scratch or NULL
 int sf_launch_global_cov(const double* wave, int n, double amp, double ls, double* out, hipStream_t s);
 int sf_launch_local_cov(const double* wave, int n, double amp, double mu, double sigma, int accumulate,
                         double* out, hipStream_t s);

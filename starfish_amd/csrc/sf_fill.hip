@@ -305,22 +305,47 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
 // The element formulas are those of sf_matern_elem / sf_local_elem with the per-walker divisions
 // hoisted into reciprocals and cos(pi x) evaluated as cospi(x) (differences ~1e-16 relative, far inside
 // the 1e-10 covariance tolerance; the dense fill keeps the reference's exact operation order).
+// On a log-uniform wavelength grid (lambda_i = lambda_0 e^(i delta): every synthetic order, rectified
+// spectra) the metric of the global kernel depends on the offset only, (l_i - l_j)/(l_i + l_j) =
+// tanh((i-j) delta/2), so K_global is one value per diagonal: tabulated here per walker from a pair in
+// the middle of the order (gtab[b][d], d <= ws; the extra entry feeds the bandwidth probe).  Differences
+// to the per-entry evaluation are at the level of the rounding of the grid itself (~3e-11 relative in r).
+__global__ __launch_bounds__(256) void k_band_gtab(sf_fill_args a, double* __restrict__ gtab, int ws) {
+    const int b = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+    if (d > ws) return;
+    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
+    const double amp = exp(P[a.off_global]), ls = exp(P[a.off_global + 1]);
+    const int i = min(a.n - 1, a.n / 2 + d / 2), j = i - d;
+    double v = 0.0;
+    if (j >= 0) {
+        const double r0 = 6 * ls;
+        const double r = SF_C_KMS / 2 * fabs((a.wave[j] - a.wave[i]) / (a.wave[j] + a.wave[i]));
+        if (r <= r0) {
+            const double t = 1.7320508075688772 / ls * r;
+            v = (0.5 + 0.5 * cospi(r / r0)) * amp * (1 + t) * exp(-t);
+        }
+    }
+    gtab[(int64_t)b * (ws + 1) + d] = v;
+}
+
+#define SF_BF_ROWS 32
 __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __restrict__ band, int ws, int ldb,
-                                                   int64_t sband, int* __restrict__ info) {
+                                                   int64_t sband, int* __restrict__ info,
+                                                   const double* __restrict__ gtab) {
     // per-walker constants once per block: exp() of the hyper-parameters (spectrum_model.py:343-357)
     __shared__ double s_glob[4];                 // amp, r0, 1/r0, sqrt(3)/ls
     __shared__ double s_loc[SF_MAX_LOCAL][6];    // mu, amp, r0, 1/r0, -0.5/sigma^2, c/mu
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, tid = threadIdx.x;
     const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
-    if (threadIdx.x == 0 && a.has_global) {
+    if (tid == 0 && a.has_global) {
         const double amp = exp(P[a.off_global]), ls = exp(P[a.off_global + 1]);
         s_glob[0] = amp;
         s_glob[1] = 6 * ls;
         s_glob[2] = 1.0 / (6 * ls);
         s_glob[3] = 1.7320508075688772 / ls;
     }
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + a.n_local) {
-        const int k = threadIdx.x - 64;
+    if (tid >= 64 && tid < 64 + a.n_local) {
+        const int k = tid - 64;
         const double sig = exp(P[a.off_local + 3 * k + 2]);
         s_loc[k][0] = P[a.off_local + 3 * k];
         s_loc[k][1] = exp(P[a.off_local + 3 * k + 1]);
@@ -330,19 +355,24 @@ __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __res
         s_loc[k][5] = SF_C_KMS / s_loc[k][0];
     }
     __syncthreads();
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (int64_t)a.npad * ws) return;
-    const int i = (int)(e / ws), d = (int)(e - (int64_t)i * ws);
-    const int j = i - d;
-    double v = 0.0;
-    if (i >= a.n) {
-        v = (d == 0) ? 1.0 : 0.0;
-    } else if (j >= 0) {
+    // SF_BF_ROWS rows per block (the exp() prologue is amortised), one wave per row at a time, 64 lanes
+    // along the diagonals of the row (coalesced stores, no index division)
+    const int lane = tid & 63;
+    const double* __restrict__ gt = gtab ? gtab + (int64_t)b * (ws + 1) : nullptr;
+    for (int i = blockIdx.x * SF_BF_ROWS + (tid >> 6); i < min(a.npad, (int)(blockIdx.x + 1) * SF_BF_ROWS); i += 4) {
+        double* __restrict__ dst = band + (int64_t)b * sband + (int64_t)i * ldb;
+        if (i >= a.n) {
+            for (int d = lane; d < ws; d += 64) dst[d] = (d == 0) ? 1.0 : 0.0;  // identity padding
+            continue;
+        }
         const double w_row = a.wave[i];
         auto structured = [&](int col, bool& any) {
             const double w_col = a.wave[col];
             double acc = 0.0;
-            if (a.has_global) {
+            if (a.has_global && gt) {
+                acc = gt[i - col];
+                any = any || acc != 0.0;
+            } else if (a.has_global) {
                 const double r = SF_C_KMS / 2 * fabs((w_col - w_row) / (w_col + w_row));
                 if (r <= s_glob[1]) {
                     const double t = s_glob[3] * r;
@@ -362,27 +392,34 @@ __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __res
             }
             return acc;
         };
-        bool any = false;
-        const double k = structured(j, any);
-        if (d == 0) {
-            const double sg = a.sigma[i];
-            v = sg * sg;
-            v = v + k;
-            if (a.add_jitter) v = v + SF_JITTER;
-        } else {
-            v = k;
-        }
-        if (d == ws - 1 && j >= 1) {
-            bool outside = false;
-            (void)structured(j - 1, outside);
-            if (outside) atomicCAS(info + b, 0, SF_INFO_BANDWIDTH);
+        for (int d = lane; d < ws; d += 64) {
+            const int j = i - d;
+            double v = 0.0;
+            if (j >= 0) {
+                bool any = false;
+                const double k = structured(j, any);
+                if (d == 0) {
+                    const double sg = a.sigma[i];
+                    v = sg * sg;
+                    v = v + k;
+                    if (a.add_jitter) v = v + SF_JITTER;
+                } else {
+                    v = k;
+                }
+                if (d == ws - 1 && j >= 1) {
+                    // first diagonal outside the storage: non-zero -> the caller's half-width is too small
+                    bool outside = false;
+                    (void)structured(j - 1, outside);
+                    if (outside) atomicCAS(info + b, 0, SF_INFO_BANDWIDTH);
+                }
+            }
+            dst[d] = v;
         }
     }
-    band[(int64_t)b * sband + (int64_t)i * ldb + d] = v;
 }
 
 int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int ldb, int64_t sband, int* info,
-                        hipStream_t s) {
+                        double* gtab, hipStream_t s) {
     if (a.n_local > SF_MAX_LOCAL) {
         sf_set_error("at most %d local kernels are supported", SF_MAX_LOCAL);
         return SF_EINVAL;
@@ -391,9 +428,13 @@ int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int 
         sf_set_error("the banded solver needs a strictly increasing wavelength grid");
         return SF_EINVAL;
     }
-    const int64_t total = (int64_t)a.npad * ws;
-    hipLaunchKernelGGL(k_band_fill, dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, s, a, band, ws, ldb,
-                       sband, info);
+    const bool table = gtab && a.has_global && a.loguniform && 2 * ws < a.n;
+    if (table) {
+        hipLaunchKernelGGL(k_band_gtab, dim3((ws + 256) / 256, B), dim3(256), 0, s, a, gtab, ws);
+        SF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_band_fill, dim3((unsigned)((a.npad + SF_BF_ROWS - 1) / SF_BF_ROWS), B), dim3(256), 0, s, a, band, ws, ldb, sband,
+                       info, table ? (const double*)gtab : nullptr);
     SF_LAUNCH_CHECK();
     return SF_OK;
 }
