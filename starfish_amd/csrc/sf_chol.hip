@@ -584,6 +584,187 @@ __global__ __launch_bounds__(256) void k_panel_finish(const double* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Diagonal-block step of one panel as ONE launch on the matrix cores (one workgroup of 8 waves per
+// matrix): L_kk and its inverse for the pw x pw block (pw <= 256) in 16-column steps.
+//   S1  wave 0: 16 x 16 Cholesky + inverse F in the MFMA accumulator layout (column j of the symmetric
+//       block is register j/4 of quarter j%4 = a K-slice of the MFMA operands, so every rank-1
+//       elimination is one MFMA without data movement; pivots from scalars so the rsqrt chain overlaps
+//       the matrix core);
+//   S2  block column k is solved as a product with F: the rows of the block below (-> L, written to the
+//       matrix) and the rows of the "identity block" E (-> W = L_kk^-T, written transposed to Wt); the
+//       results stay in LDS as operands;
+//   S3  trailing update of the remaining blocks of M and E (global read-modify-write through L2,
+//       loads of four blocks in flight per wave).
+// The identity block is implicit (row block e of E starts at step e with C = 0 and X = F^T).  Finally
+// z_k = L_kk^-1 r_k as a product with the explicit inverse.  Replaces k_set_identity + 4 x (k_potrf_leaf,
+// k_trsm_leaf, K=64 k_gemm_nt) + k_panel_finish: one scheduling wait on the contended chip instead of 13.
+#define DBS (16 * 17)
+#define DLD 17
+__device__ __forceinline__ double sfd_rsqrt(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    double e = __builtin_fma(-h * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-h * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+
+__global__ __launch_bounds__(512, 2) void k_diag_mfma(double* __restrict__ T, int64_t sT, int pw,
+                                                      int* __restrict__ info, int info_off,
+                                                      double* __restrict__ rhs, int ldr,
+                                                      double* __restrict__ Cdiag, int ldc, int64_t sC,
+                                                      double* __restrict__ Wt, int64_t sW) {
+    __shared__ double PM[16 * DBS];  // solved blocks of column k: rows of the matrix block ...
+    __shared__ double PE[16 * DBS];  // ... and rows of the inverse (E) block
+    __shared__ double Fb[DBS];       // inverse of the current 16 x 16 diagonal factor
+    __shared__ double rz[256];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nb = pw >> 4;
+    double* Tb = T + (int64_t)b * sT;
+    double* Eb = Tb + (int64_t)pw * SF_LDT;
+    double* Cb = Cdiag + (int64_t)b * sC;
+    double* Wb = Wt + (int64_t)b * sW;
+
+    // Wt is lower triangular: zero the blocks above the diagonal (the buffer alternates between panels)
+    for (int e = tid; e < nb * nb * 256; e += 512) {
+        const int blk = e >> 8, bc = blk / nb, be = blk - bc * nb;
+        if (be > bc) Wb[(int64_t)(bc * 16 + ((e >> 4) & 15)) * SF_LDT + be * 16 + (e & 15)] = 0.0;
+    }
+    int bad = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int m = nb - 1 - k;
+        // ---- S1
+        if (wave == 0) {
+            sf_d4 acc, f, lt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = lq + 4 * r;
+                acc[r] = Tb[(int64_t)(16 * k + max(row, l15)) * SF_LDT + 16 * k + min(row, l15)];
+                f[r] = row == l15 ? 1.0 : 0.0;
+                lt[r] = 0.0;
+            }
+            double p = sf_readlane_d(acc[0], 0);
+            double pkeep = 1.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int qj = j & 3, rj = j >> 2;
+                pkeep = lane == j ? p : pkeep;
+                const double rs = sfd_rsqrt(p);
+                const bool in_q = lq == qj;
+                const double v = (in_q && l15 > j) ? acc[rj] * rs : 0.0;  // l_ij, i = l15 > j
+                const double g = in_q ? f[rj] * rs : 0.0;                 // row j of F, scaled
+                if (in_q) {
+                    f[rj] = g;
+                    lt[rj] = l15 == j ? p * rs : v;  // L^T[j][i]
+                }
+                if (j + 1 < 16) {
+                    const double an = sf_readlane_d(acc[(j + 1) >> 2], ((j + 1) & 3) * 16 + j + 1);
+                    const double vn = sf_readlane_d(v, qj * 16 + j + 1);
+                    p = __builtin_fma(-vn, vn, an);
+                }
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, acc, 0, 0, 0);
+                f = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, g, f, 0, 0, 0);
+            }
+            const unsigned long long neg = __ballot(lane < 16 && !(pkeep > 0.0));
+            if (neg && !bad) bad = 16 * k + __ffsll((long long)neg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = lq + 4 * r;
+                Fb[row * DLD + l15] = f[r];
+                PE[k * DBS + l15 * DLD + row] = f[r];  // X of the identity row block k: F^T
+                Wb[(int64_t)(16 * k + row) * SF_LDT + 16 * k + l15] = f[r];  // diagonal block of L_kk^-1
+                if (l15 >= row) Cb[(int64_t)(16 * k + l15) * ldc + 16 * k + row] = lt[r];  // L[i][j]
+            }
+        }
+        __syncthreads();
+        // ---- S2: X = P F^T for the blocks of column k
+        for (int t = wave; t < m + k; t += 8) {
+            const bool isM = t < m;
+            const int ib = isM ? k + 1 + t : t - m;
+            const double* src = (isM ? Tb : Eb) + (int64_t)(16 * ib) * SF_LDT + 16 * k;
+            sf_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(src[(int64_t)l15 * SF_LDT + kk * 4 + lq],
+                                                           Fb[l15 * DLD + kk * 4 + lq], acc, 0, 0, 0);
+            double* P = (isM ? PM : PE) + ib * DBS;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = lq + 4 * r;
+                P[row * DLD + l15] = acc[r];
+                if (isM) Cb[(int64_t)(16 * ib + row) * ldc + 16 * k + l15] = acc[r];      // L
+                else Wb[(int64_t)(16 * k + l15) * SF_LDT + 16 * ib + row] = acc[r];        // (L^-T)^T
+            }
+        }
+        __syncthreads();
+        // ---- S3: trailing update, four blocks in flight per wave
+        const int npM = m * (m + 1) / 2, np = npM + (k + 1) * m;
+        for (int p0 = wave; p0 < np; p0 += 32) {
+            double* cp[4];
+            const double *pi[4], *pj[4];
+            bool ok[4], zero[4];
+            sf_d4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + 8 * u;
+                ok[u] = p < np;
+                zero[u] = false;
+                cp[u] = Tb;
+                pi[u] = pj[u] = PM;
+                if (ok[u]) {
+                    if (p < npM) {
+                        int I = (int)((sqrtf(8.0f * p + 1.0f) - 1.0f) * 0.5f);
+                        while (I * (I + 1) / 2 > p) --I;
+                        while ((I + 1) * (I + 2) / 2 <= p) ++I;
+                        const int J = p - I * (I + 1) / 2;
+                        const int i = k + 1 + I, j = k + 1 + J;
+                        cp[u] = Tb + (int64_t)(16 * i) * SF_LDT + 16 * j;
+                        pi[u] = PM + i * DBS;
+                        pj[u] = PM + j * DBS;
+                    } else {
+                        const int q = p - npM, e = q / m, j = k + 1 + (q - e * m);
+                        cp[u] = Eb + (int64_t)(16 * e) * SF_LDT + 16 * j;
+                        pi[u] = PE + e * DBS;
+                        pj[u] = PM + j * DBS;
+                        zero[u] = e == k;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[u][r] = (ok[u] && !zero[u]) ? cp[u][(int64_t)(lq + 4 * r) * SF_LDT + l15] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pi[u][l15 * DLD + kk * 4 + lq],
+                                                                  pj[u][l15 * DLD + kk * 4 + lq], acc[u], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cp[u][(int64_t)(lq + 4 * r) * SF_LDT + l15] = acc[u][r];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && bad && info && info[b] == 0) info[b] = info_off + bad;
+    // ---- z_k = L_kk^-1 r_k with the explicit inverse
+    if (rhs) {
+        double* rb = rhs + (int64_t)b * ldr;
+        for (int i = tid; i < pw; i += 512) rz[i] = rb[i];
+        __syncthreads();
+        for (int i = tid; i < pw; i += 512) {
+            const double* wrow = Wb + (int64_t)i * SF_LDT;
+            double acc = 0.0;
+            for (int j = 0; j <= i; ++j) acc = __builtin_fma(wrow[j], rz[j], acc);
+            rb[i] = acc;
+        }
+    }
+}
+
 // Whole diagonal-block step of one panel in ONE launch (one workgroup per matrix), so that it can run
 // on the side stream next to the big MFMA launches without waiting for CU slots a dozen times:
 //   identity block; for each 64-column leaf: register Cholesky by wave 0 (as k_potrf_leaf, with the
@@ -895,7 +1076,12 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
             SF_HIP(hipEventRecord(e_ur, s));
         }
         // ---- D + F on the side stream (T rows [0, pw) already hold the fully updated diagonal block)
-        if (fused_diag) {
+        static const bool leaf_diag = getenv("SF_LEAF_DIAG") != nullptr;  // tuning aid: the 13-launch chain
+        if (!leaf_diag && !fused_diag) {
+            hipLaunchKernelGGL(k_diag_mfma, dim3(batch), dim3(512), 0, c, T, sT, pw, info, k0,
+                               rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
+            SF_LAUNCH_CHECK();
+        } else if (fused_diag) {
             hipLaunchKernelGGL(k_panel_diag, dim3(batch), dim3(256), 0, c, T, sT, pw, info, k0,
                                rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
             SF_LAUNCH_CHECK();
