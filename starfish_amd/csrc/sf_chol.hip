@@ -585,18 +585,20 @@ __global__ __launch_bounds__(256) void k_panel_finish(const double* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// Diagonal-block step of one panel as ONE launch on the matrix cores (one workgroup of 8 waves per
-// matrix): L_kk and its inverse for the pw x pw block (pw <= 256) in 16-column steps.
-//   S1  wave 0: 16 x 16 Cholesky + inverse F in the MFMA accumulator layout (column j of the symmetric
-//       block is register j/4 of quarter j%4 = a K-slice of the MFMA operands, so every rank-1
-//       elimination is one MFMA without data movement; pivots from scalars so the rsqrt chain overlaps
-//       the matrix core);
-//   S2  block column k is solved as a product with F: the rows of the block below (-> L, written to the
-//       matrix) and the rows of the "identity block" E (-> W = L_kk^-T, written transposed to Wt); the
-//       results stay in LDS as operands;
-//   S3  trailing update of the remaining blocks of M and E (global read-modify-write through L2,
-//       loads of four blocks in flight per wave).
-// The identity block is implicit (row block e of E starts at step e with C = 0 and X = F^T).  Finally
+// Diagonal-block step of one panel as ONE launch on the matrix cores (one workgroup of 16 waves per
+// matrix, one 16 x 16 block of the current block column per wave): L_kk and its inverse for the pw x pw block (pw <= 256), LEFT-looking over 16-column block
+// columns so that nothing is read-modify-written in memory:
+//   U  every wave accumulates its blocks of column k in registers:  M(i,k) - sum_{j<k} L(i,j) L(k,j)^T
+//      for the rows of the matrix block and  - sum_{e<=j<k} X(e,j) L(k,j)^T  for the rows of the "identity
+//      block" E (whose solved rows X = rows of W = L_kk^-T).  A operands stream from L2, the row L(k,:)
+//      shared by the whole column is staged in LDS once;
+//   P  wave 0, which owns M(k,k), factorises it and inverts the factor in the MFMA accumulator layout
+//      (column j of the symmetric block is register j/4 of quarter j%4 = a K-slice of the MFMA operands,
+//      so every rank-1 elimination is one MFMA without data movement; pivots from scalars so that the
+//      rsqrt chain overlaps the matrix core);
+//   X  every wave solves the blocks it still holds as a product with the 16 x 16 inverse F and writes
+//      them out: L to the matrix (and in place, as operand of later columns), W transposed to Wt.
+// The identity block is implicit (row block e of E starts at column e with X = F^T).  Finally
 // z_k = L_kk^-1 r_k as a product with the explicit inverse.  Replaces k_set_identity + 4 x (k_potrf_leaf,
 // k_trsm_leaf, K=64 k_gemm_nt) + k_panel_finish: one scheduling wait on the contended chip instead of 13.
 #define DBS (16 * 17)
@@ -611,13 +613,13 @@ __device__ __forceinline__ double sfd_rsqrt(double p) {
     return y;
 }
 
-__global__ __launch_bounds__(512, 2) void k_diag_mfma(double* __restrict__ T, int64_t sT, int pw,
+__global__ __launch_bounds__(1024) void k_diag_mfma(double* __restrict__ T, int64_t sT, int pw,
                                                       int* __restrict__ info, int info_off,
                                                       double* __restrict__ rhs, int ldr,
                                                       double* __restrict__ Cdiag, int ldc, int64_t sC,
                                                       double* __restrict__ Wt, int64_t sW) {
-    __shared__ double PM[16 * DBS];  // solved blocks of column k: rows of the matrix block ...
-    __shared__ double PE[16 * DBS];  // ... and rows of the inverse (E) block
+    __shared__ double LK[15 * DBS];  // L(k, j), j < k: the B operand of the whole block column
+    __shared__ double ST[16 * DBS];  // per-wave staging block (accumulator layout -> operand layout)
     __shared__ double Fb[DBS];       // inverse of the current 16 x 16 diagonal factor
     __shared__ double rz[256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -628,26 +630,87 @@ __global__ __launch_bounds__(512, 2) void k_diag_mfma(double* __restrict__ T, in
     double* Eb = Tb + (int64_t)pw * SF_LDT;
     double* Cb = Cdiag + (int64_t)b * sC;
     double* Wb = Wt + (int64_t)b * sW;
+    double* st = ST + wave * DBS;
 
     // Wt is lower triangular: zero the blocks above the diagonal (the buffer alternates between panels)
-    for (int e = tid; e < nb * nb * 256; e += 512) {
+    for (int e = tid; e < nb * nb * 256; e += 1024) {
         const int blk = e >> 8, bc = blk / nb, be = blk - bc * nb;
         if (be > bc) Wb[(int64_t)(bc * 16 + ((e >> 4) & 15)) * SF_LDT + be * 16 + (e & 15)] = 0.0;
     }
     int bad = 0;
     for (int k = 0; k < nb; ++k) {
-        const int m = nb - 1 - k;
-        // ---- S1
+        const int m = nb - 1 - k;  // matrix row blocks below the diagonal block
+        // ---- stage L(k, 0..k-1) (final since the previous columns) in LDS
+        for (int e = tid; e < k * 256; e += 1024) {
+            const int j = e >> 8, r = (e >> 4) & 15, cc = e & 15;
+            LK[j * DBS + r * DLD + cc] = Tb[(int64_t)(16 * k + r) * SF_LDT + 16 * j + cc];
+        }
+        __syncthreads();
+        // ---- U: block of this wave: t = 0 -> M(k,k), 1..m -> M(k+t,k), then E(e,k)
+        sf_d4 acc[1];
+        int kind[1];  // 0 none, 1 matrix row block, 2 inverse row block
+        int ibk[1];
+        {
+            constexpr int u = 0;
+            const int t = wave;
+            kind[u] = 0;
+            ibk[u] = 0;
+            acc[u] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+            if (t <= m + k) {
+                const bool isM = t <= m;
+                const int ib = isM ? k + t : t - m - 1;
+                kind[u] = isM ? 1 : 2;
+                ibk[u] = ib;
+                const double* rowp = (isM ? Tb : Eb) + (int64_t)(16 * ib) * SF_LDT;
+                if (isM) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = lq + 4 * r;
+                        // the diagonal block is read symmetrically from its lower triangle
+                        acc[u][r] = (t == 0) ? rowp[(int64_t)max(row, l15) * SF_LDT + 16 * k + min(row, l15)]
+                                             : rowp[(int64_t)row * SF_LDT + 16 * k + l15];
+                    }
+                }
+                const int j0 = isM ? 0 : ib;  // X(e, j) exists for j >= e
+                // K is a summation index: lane (l15, lq) takes the four CONTIGUOUS columns 4 lq .. 4 lq + 3
+                // of its row (two 16-byte loads, full 128-B lines per 4 lanes) and MFMA kk uses element kk, i.e.
+                // slice lq of instruction kk stands for k = 4 lq + kk -- in both operands.
+                const double2* ap = (const double2*)(rowp + (int64_t)l15 * SF_LDT + 4 * lq);
+                // A fragments stream from L2: four block columns in flight (clamped loads past the end)
+                double2 av[4][2];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int jj = min(j0 + d, max(k - 1, 0));
+                    av[d][0] = ap[8 * jj];
+                    av[d][1] = ap[8 * jj + 1];
+                }
+                for (int j = j0; j < k; ++j) {
+                    // rotating register window: block column j is consumed, j + 4 is requested
+                    const double* lk = LK + j * DBS + l15 * DLD + 4 * lq;
+                    const double a4[4] = {av[0][0].x, av[0][0].y, av[0][1].x, av[0][1].y};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a4[kk], lk[kk], acc[u], 0, 0, 0);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        av[d][0] = av[d + 1][0];
+                        av[d][1] = av[d + 1][1];
+                    }
+                    const int jj = min(j + 4, max(k - 1, 0));
+                    av[3][0] = ap[8 * jj];
+                    av[3][1] = ap[8 * jj + 1];
+                }
+            }
+        }
+        // ---- P: wave 0 holds the updated diagonal block in acc[0]
         if (wave == 0) {
-            sf_d4 acc, f, lt;
+            sf_d4 a0 = acc[0], f, lt;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = lq + 4 * r;
-                acc[r] = Tb[(int64_t)(16 * k + max(row, l15)) * SF_LDT + 16 * k + min(row, l15)];
-                f[r] = row == l15 ? 1.0 : 0.0;
+                f[r] = (lq + 4 * r) == l15 ? 1.0 : 0.0;
                 lt[r] = 0.0;
             }
-            double p = sf_readlane_d(acc[0], 0);
+            double p = sf_readlane_d(a0[0], 0);
             double pkeep = 1.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -655,18 +718,18 @@ __global__ __launch_bounds__(512, 2) void k_diag_mfma(double* __restrict__ T, in
                 pkeep = lane == j ? p : pkeep;
                 const double rs = sfd_rsqrt(p);
                 const bool in_q = lq == qj;
-                const double v = (in_q && l15 > j) ? acc[rj] * rs : 0.0;  // l_ij, i = l15 > j
-                const double g = in_q ? f[rj] * rs : 0.0;                 // row j of F, scaled
+                const double v = (in_q && l15 > j) ? a0[rj] * rs : 0.0;  // l_ij, i = l15 > j
+                const double g = in_q ? f[rj] * rs : 0.0;                // row j of F, scaled
                 if (in_q) {
                     f[rj] = g;
                     lt[rj] = l15 == j ? p * rs : v;  // L^T[j][i]
                 }
                 if (j + 1 < 16) {
-                    const double an = sf_readlane_d(acc[(j + 1) >> 2], ((j + 1) & 3) * 16 + j + 1);
+                    const double an = sf_readlane_d(a0[(j + 1) >> 2], ((j + 1) & 3) * 16 + j + 1);
                     const double vn = sf_readlane_d(v, qj * 16 + j + 1);
                     p = __builtin_fma(-vn, vn, an);
                 }
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, acc, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, a0, 0, 0, 0);
                 f = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, g, f, 0, 0, 0);
             }
             const unsigned long long neg = __ballot(lane < 16 && !(pkeep > 0.0));
@@ -675,77 +738,36 @@ __global__ __launch_bounds__(512, 2) void k_diag_mfma(double* __restrict__ T, in
             for (int r = 0; r < 4; ++r) {
                 const int row = lq + 4 * r;
                 Fb[row * DLD + l15] = f[r];
-                PE[k * DBS + l15 * DLD + row] = f[r];  // X of the identity row block k: F^T
                 Wb[(int64_t)(16 * k + row) * SF_LDT + 16 * k + l15] = f[r];  // diagonal block of L_kk^-1
-                if (l15 >= row) Cb[(int64_t)(16 * k + l15) * ldc + 16 * k + row] = lt[r];  // L[i][j]
+                // X of the identity row block k is F^T: operand of later columns
+                Eb[(int64_t)(16 * k + l15) * SF_LDT + 16 * k + row] = f[r];
+                if (l15 >= row) {
+                    Cb[(int64_t)(16 * k + l15) * ldc + 16 * k + row] = lt[r];          // L[i][j] -> matrix
+                    Tb[(int64_t)(16 * k + l15) * SF_LDT + 16 * k + row] = lt[r];        // and in place
+                }
             }
+            kind[0] = 0;
         }
         __syncthreads();
-        // ---- S2: X = P F^T for the blocks of column k
-        for (int t = wave; t < m + k; t += 8) {
-            const bool isM = t < m;
-            const int ib = isM ? k + 1 + t : t - m;
-            const double* src = (isM ? Tb : Eb) + (int64_t)(16 * ib) * SF_LDT + 16 * k;
-            sf_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        // ---- X: solve the blocks still held in registers, write them out
+#pragma unroll
+        for (int u = 0; u < 1; ++u) {
+            if (kind[u] == 0) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[(lq + 4 * r) * DLD + l15] = acc[u][r];
+            sf_d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(src[(int64_t)l15 * SF_LDT + kk * 4 + lq],
-                                                           Fb[l15 * DLD + kk * 4 + lq], acc, 0, 0, 0);
-            double* P = (isM ? PM : PE) + ib * DBS;
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(st[l15 * DLD + kk * 4 + lq], Fb[l15 * DLD + kk * 4 + lq], x,
+                                                         0, 0, 0);
+            const int ib = ibk[u];
+            double* rowp = (kind[u] == 1 ? Tb : Eb) + (int64_t)(16 * ib) * SF_LDT + 16 * k;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = lq + 4 * r;
-                P[row * DLD + l15] = acc[r];
-                if (isM) Cb[(int64_t)(16 * ib + row) * ldc + 16 * k + l15] = acc[r];      // L
-                else Wb[(int64_t)(16 * k + l15) * SF_LDT + 16 * ib + row] = acc[r];        // (L^-T)^T
-            }
-        }
-        __syncthreads();
-        // ---- S3: trailing update, four blocks in flight per wave
-        const int npM = m * (m + 1) / 2, np = npM + (k + 1) * m;
-        for (int p0 = wave; p0 < np; p0 += 32) {
-            double* cp[4];
-            const double *pi[4], *pj[4];
-            bool ok[4], zero[4];
-            sf_d4 acc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = p0 + 8 * u;
-                ok[u] = p < np;
-                zero[u] = false;
-                cp[u] = Tb;
-                pi[u] = pj[u] = PM;
-                if (ok[u]) {
-                    if (p < npM) {
-                        int I = (int)((sqrtf(8.0f * p + 1.0f) - 1.0f) * 0.5f);
-                        while (I * (I + 1) / 2 > p) --I;
-                        while ((I + 1) * (I + 2) / 2 <= p) ++I;
-                        const int J = p - I * (I + 1) / 2;
-                        const int i = k + 1 + I, j = k + 1 + J;
-                        cp[u] = Tb + (int64_t)(16 * i) * SF_LDT + 16 * j;
-                        pi[u] = PM + i * DBS;
-                        pj[u] = PM + j * DBS;
-                    } else {
-                        const int q = p - npM, e = q / m, j = k + 1 + (q - e * m);
-                        cp[u] = Eb + (int64_t)(16 * e) * SF_LDT + 16 * j;
-                        pi[u] = PE + e * DBS;
-                        pj[u] = PM + j * DBS;
-                        zero[u] = e == k;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[u][r] = (ok[u] && !zero[u]) ? cp[u][(int64_t)(lq + 4 * r) * SF_LDT + l15] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!ok[u]) continue;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pi[u][l15 * DLD + kk * 4 + lq],
-                                                                  pj[u][l15 * DLD + kk * 4 + lq], acc[u], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cp[u][(int64_t)(lq + 4 * r) * SF_LDT + l15] = acc[u][r];
+                rowp[(int64_t)row * SF_LDT + l15] = x[r];  // in place: operand of the later columns
+                if (kind[u] == 1) Cb[(int64_t)(16 * ib + row) * ldc + 16 * k + l15] = x[r];  // L
+                else Wb[(int64_t)(16 * k + l15) * SF_LDT + 16 * ib + row] = x[r];             // (L^-T)^T
             }
         }
         __syncthreads();
@@ -754,13 +776,13 @@ __global__ __launch_bounds__(512, 2) void k_diag_mfma(double* __restrict__ T, in
     // ---- z_k = L_kk^-1 r_k with the explicit inverse
     if (rhs) {
         double* rb = rhs + (int64_t)b * ldr;
-        for (int i = tid; i < pw; i += 512) rz[i] = rb[i];
+        for (int i = tid; i < pw; i += 1024) rz[i] = rb[i];
         __syncthreads();
-        for (int i = tid; i < pw; i += 512) {
+        for (int i = tid; i < pw; i += 1024) {
             const double* wrow = Wb + (int64_t)i * SF_LDT;
-            double acc = 0.0;
-            for (int j = 0; j <= i; ++j) acc = __builtin_fma(wrow[j], rz[j], acc);
-            rb[i] = acc;
+            double zacc = 0.0;
+            for (int j = 0; j <= i; ++j) zacc = __builtin_fma(wrow[j], rz[j], zacc);
+            rb[i] = zacc;
         }
     }
 }
@@ -917,9 +939,13 @@ __global__ __launch_bounds__(256) void k_panel_diag(double* __restrict__ T, int6
     }
 }
 
+// The per-matrix scratch strides are skewed by a few hundred bytes: with strides that are multiples of
+// 32 KiB every workgroup of the batch touches the same HBM channel / L2 bank at the same time (measured:
+// 3.6 us per dependent load in k_diag_mfma before the skew).
+#define SF_TSKEW 40
 size_t sf_potrf_work_doubles(int n, int batch) {
     const size_t b = (size_t)batch;
-    return b * SF_LTB_DOUBLES + b * (size_t)(n + SF_NB) * SF_LDT + 2 * b * (size_t)SF_NB * SF_LDT + 64;
+    return b * SF_LTB_DOUBLES + b * ((size_t)(n + SF_NB) * SF_LDT + SF_TSKEW) + 2 * b * ((size_t)SF_NB * SF_LDT + SF_TSKEW) + 64;
 }
 
 // ---- two-stream lookahead ---------------------------------------------------------------------
@@ -986,9 +1012,9 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     }
     double* ltbuf = work;
     double* T = ltbuf + (size_t)batch * SF_LTB_DOUBLES;
-    const int64_t sT = (int64_t)(n + SF_NB) * SF_LDT;
+    const int64_t sT = (int64_t)(n + SF_NB) * SF_LDT + SF_TSKEW;
     double* Wt2 = T + (size_t)batch * sT;  // two W^T buffers, alternating by panel parity
-    const int64_t sW = (int64_t)SF_NB * SF_LDT;
+    const int64_t sW = (int64_t)SF_NB * SF_LDT + SF_TSKEW;
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
 
     hipStream_t c = nullptr;  // side ("critical chain") stream
@@ -1078,7 +1104,7 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
         // ---- D + F on the side stream (T rows [0, pw) already hold the fully updated diagonal block)
         static const bool leaf_diag = getenv("SF_LEAF_DIAG") != nullptr;  // tuning aid: the 13-launch chain
         if (!leaf_diag && !fused_diag) {
-            hipLaunchKernelGGL(k_diag_mfma, dim3(batch), dim3(512), 0, c, T, sT, pw, info, k0,
+            hipLaunchKernelGGL(k_diag_mfma, dim3(batch), dim3(1024), 0, c, T, sT, pw, info, k0,
                                rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
             SF_LAUNCH_CHECK();
         } else if (fused_diag) {
