@@ -1021,6 +1021,7 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     SF_TRY(side_stream(&c));
     static const bool no_lookahead = getenv("SF_NO_LOOKAHEAD") != nullptr;  // tuning aid: single stream
     static const bool fused_diag = getenv("SF_FUSED_DIAG") != nullptr;      // tuning aid: one-launch D
+    static const int rlazy = getenv("SF_RLAZY") ? atoi(getenv("SF_RLAZY")) : 1;  // tuning aid; measured: no gain for 2, 4, 8
     if (no_lookahead) c = s;
     hipEvent_t e_fork, e_gt_prev = nullptr;
     SF_TRY(next_event(&e_fork));
@@ -1169,14 +1170,19 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
         SF_HIP(hipEventRecord(e_gt, c));
         e_gt_prev = e_gt;
         // next diagonal block: apply this panel's columns and park it in the panel scratch
-        SF_TRY(launch_r(k1, ntop, k0, pw, T, SF_LDT, sT, 0, c));
+        // (the diagonal blocks after the next one are brought up to date only every `rlazy` panels, with a
+        // correspondingly longer K: their read-modify-write traffic is what bounds those launches; the next
+        // block therefore may still miss the last few panels)
+        const int pend0 = (panel / rlazy) * rlazy * SF_NB;  // first panel column not yet applied to block k+1
+        SF_TRY(launch_r(k1, ntop, pend0, k1 - pend0, T, SF_LDT, sT, 0, c));
         if (nbelow > ntop) {
             SF_HIP(hipStreamWaitEvent(s, e_f, 0));
             SF_TRY(launch_g(ntop, nbelow - ntop, s));
-            // the diagonal blocks after the next one are updated in place
+            // the diagonal blocks after the next one are updated in place, every `rlazy` panels
             const int j0 = k1 + ntop;
-            SF_TRY(launch_r(j0, n - j0, k0, pw, A + (int64_t)j0 * lda + j0, lda, stride,
-                            (int64_t)SF_NB * lda + SF_NB, s));
+            if ((panel + 1) % rlazy == 0 && j0 < n)
+                SF_TRY(launch_r(j0, n - j0, pend0, k1 - pend0, A + (int64_t)j0 * lda + j0, lda, stride,
+                                (int64_t)SF_NB * lda + SF_NB, s));
         }
     }
     // join: the caller's stream continues only after the side chain is done
