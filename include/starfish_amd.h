@@ -215,7 +215,7 @@ int sf_loglike_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const doubl
 /* ---- structure-exploiting solver -----------------------------------
  * Same value as sf_loglike_batch, computed without ever forming the N x N matrix: the covariance of
  * spectrum_model.py:334-363 is  C = Bd + Y^T Y  with Bd = sigma^2 + K_global + K_local + jitter
- * banded (the `r <= r0` masks of models/kernels.py:33,78 give it a half-width of ~6 ls/dv pixels)
+ * banded (the `r <= r0` masks of models/kernels.py:33,78 give it a half-width of ~24 ls/dv pixels)
  * and Y^T Y = X^T Sigma_w^-1 X of rank m, so a banded Cholesky plus the m x m Woodbury capacitance
  * matrix give logdet C and R^T C^-1 R in O(N W^2) flops.  `halfwidth` is the caller's bound W on
  * max |i-j| over the non-zero entries of Bd (in pixels, over the whole batch); walkers whose
