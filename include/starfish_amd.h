@@ -26,8 +26,9 @@
  *     work is ordered on `stream`.  The library keeps process-global state (side stream, event pool,
  *     timing hooks): issue calls from ONE host thread per process (one process per GPU).
  *   - environment switches (tuning aids, read once): SF_NO_LOOKAHEAD=1 single-stream Cholesky,
- *     SF_FUSED_DIAG=1 one-launch diagonal-block step, SF_GEMM_256=1 / SF_GEMM_1024=1 alternative
- *     wave layouts of the MFMA update kernel (default: 512 threads, measured fastest).
+ *     SF_LEAF_DIAG=1 diagonal-block step as a chain of register-level leaf kernels instead of the
+ *     one-launch MFMA kernel, SF_GEMM_256=1 / SF_GEMM_1024=1 alternative wave layouts of the MFMA
+ *     update kernel (default: 512 threads, measured fastest), SF_BAND_NO_TWIST=1 single-sweep banded solver.
  */
 #ifndef STARFISH_AMD_H
 #define STARFISH_AMD_H

@@ -787,157 +787,6 @@ __global__ __launch_bounds__(1024) void k_diag_mfma(double* __restrict__ T, int6
     }
 }
 
-// Whole diagonal-block step of one panel in ONE launch (one workgroup per matrix), so that it can run
-// on the side stream next to the big MFMA launches without waiting for CU slots a dozen times:
-//   identity block; for each 64-column leaf: register Cholesky by wave 0 (as k_potrf_leaf, with the
-//   fused forward substitution), row-per-lane solves of all rows below (L^T broadcast from LDS), K = 64
-//   MFMA update of the remaining columns; finally L_kk -> matrix and W^T for the panel solve.
-// S = panel scratch rows [0, 2 pw): diagonal block on top, identity (-> W = L_kk^-T) below.
-__global__ __launch_bounds__(256) void k_panel_diag(double* __restrict__ T, int64_t sT, int pw,
-                                                    int* __restrict__ info, int info_off,
-                                                    double* __restrict__ rhs, int ldr,
-                                                    double* __restrict__ Cdiag, int ldc, int64_t sC,
-                                                    double* __restrict__ Wt, int64_t sW) {
-    __shared__ __attribute__((aligned(16))) double Lt[SF_LEAF * SF_LEAF];
-    __shared__ double zs[SF_LEAF];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    double* S = T + (int64_t)b * sT;
-    double* rb = rhs ? rhs + (int64_t)b * ldr : nullptr;
-
-    for (int e = tid; e < pw * pw; e += 256) {
-        const int i = e / pw, j = e - i * pw;
-        S[(int64_t)(pw + i) * SF_LDT + j] = (i == j) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-
-    for (int c = 0; c < pw; c += SF_LEAF) {
-        // ---- leaf factorisation: lane r of wave 0 owns row c + r
-        if (w == 0) {
-            double* prow = S + (int64_t)(c + lane) * SF_LDT + c;
-            double a[SF_LEAF];
-#pragma unroll
-            for (int j = 0; j < SF_LEAF; j += 2) {
-                const double2 v = *(const double2*)(prow + j);
-                a[j] = v.x;
-                a[j + 1] = v.y;
-            }
-            int bad = 0;
-            double rv = rb ? rb[c + lane] : 0.0;
-#pragma unroll
-            for (int k = 0; k < SF_LEAF; ++k) {
-                const double akk = sf_readlane_d(a[k], k);
-                if (!(akk > 0.0) && !bad) bad = info_off + c + k + 1;
-                const double d = sqrt(akk);
-                const double inv = 1.0 / d;
-                a[k] = (lane > k) ? a[k] * inv : ((lane == k) ? d : 0.0);
-                Lt[k * SF_LEAF + lane] = (lane == k) ? inv : a[k];
-                const double zk = sf_readlane_d(rv, k) * inv;
-                rv = (lane > k) ? rv - a[k] * zk : ((lane == k) ? zk : rv);
-#pragma unroll
-                for (int j = k + 1; j < SF_LEAF; ++j) {
-                    const double ljk = sf_readlane_d(a[k], j);
-                    a[j] -= a[k] * ljk;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < SF_LEAF; ++j)
-                if (j <= lane) prow[j] = a[j];
-            zs[lane] = rv;
-            if (rb) rb[c + lane] = rv;
-            if (lane == 0 && bad && info[b] == 0) info[b] = bad;
-        }
-        __syncthreads();
-
-        // ---- rows below: X L^T = A, one row per lane, 64-row chunks dealt to the 4 waves
-        const int o = c + SF_LEAF;
-        const int nrows = 2 * pw - o;
-        for (int q = w; q * SF_LEAF < nrows; q += 4) {
-            const int row = o + q * SF_LEAF + lane;
-            const bool valid = row < 2 * pw;
-            double* p = S + (int64_t)(valid ? row : 2 * pw - 1) * SF_LDT + c;
-            double x[SF_LEAF];
-#pragma unroll
-            for (int j = 0; j < SF_LEAF; j += 2) {
-                const double2 v = *(const double2*)(p + j);
-                x[j] = v.x;
-                x[j + 1] = v.y;
-            }
-#pragma unroll
-            for (int k = 0; k < SF_LEAF; ++k) {
-                x[k] *= Lt[k * SF_LEAF + k];
-                const double xk = x[k];
-#pragma unroll
-                for (int j = k + 1; j < SF_LEAF; ++j) x[j] -= xk * Lt[k * SF_LEAF + j];
-            }
-            if (valid) {
-#pragma unroll
-                for (int j = 0; j < SF_LEAF; j += 2) *(double2*)(p + j) = make_double2(x[j], x[j + 1]);
-                if (rb && row < pw) {
-                    double acc = rb[row];
-#pragma unroll
-                    for (int j = 0; j < SF_LEAF; ++j) acc -= x[j] * zs[j];
-                    rb[row] = acc;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- K = 64 update of the remaining columns: S[o:, o:pw] -= S[o:, c:o] S[o:pw, c:o]^T
-        const int Nc = pw - o;
-        if (Nc > 0) {
-            const int ntn = Nc / SF_LEAF, ntm = nrows / 32;
-            const int l15 = lane & 15, lq = lane >> 4;
-            for (int t = w; t < ntm * ntn; t += 4) {
-                const int tm = t / ntn, tn = t - tm * ntn;
-                const int r0 = o + tm * 32, c0 = o + tn * SF_LEAF;
-                if (c0 > r0 + 31) continue;  // entirely above the diagonal of the diagonal block
-                sf_d4 acc[2][4];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[mi][ni][r] = S[(int64_t)(r0 + mi * 16 + lq + 4 * r) * SF_LDT + c0 + ni * 16 + l15];
-                const double* Ab = S + (int64_t)(r0 + l15) * SF_LDT + c + lq;
-                const double* Bb = S + (int64_t)(c0 + l15) * SF_LDT + c + lq;
-#pragma unroll 4
-                for (int ks = 0; ks < SF_LEAF / 4; ++ks) {
-                    double av[2], bv[4];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) av[i] = -Ab[(int64_t)i * 16 * SF_LDT + ks * 4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bv[i] = Bb[(int64_t)i * 16 * SF_LDT + ks * 4];
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
-                }
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            S[(int64_t)(r0 + mi * 16 + lq + 4 * r) * SF_LDT + c0 + ni * 16 + l15] = acc[mi][ni][r];
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- L_kk back into the matrix; W^T (lower triangular, zero above) for the panel solve
-    double* Cb = Cdiag + (int64_t)b * sC;
-    double* Wb = Wt + (int64_t)b * sW;
-    for (int e = tid; e < pw * pw; e += 256) {
-        const int i = e / pw, j = e - i * pw;
-        if (j <= i) Cb[(int64_t)i * ldc + j] = S[(int64_t)i * SF_LDT + j];
-    }
-    for (int e = tid; e < pw * pw; e += 256) {
-        const int j = e / pw, cc = e - j * pw;  // read W[j][cc] along a row, scatter to Wt[cc][j]
-        Wb[(int64_t)cc * SF_LDT + j] = (j <= cc) ? S[(int64_t)(pw + j) * SF_LDT + cc] : 0.0;
-    }
-}
 
 // The per-matrix scratch strides are skewed by a few hundred bytes: with strides that are multiples of
 // 32 KiB every workgroup of the batch touches the same HBM channel / L2 bank at the same time (measured:
@@ -1020,7 +869,6 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     hipStream_t c = nullptr;  // side ("critical chain") stream
     SF_TRY(side_stream(&c));
     static const bool no_lookahead = getenv("SF_NO_LOOKAHEAD") != nullptr;  // tuning aid: single stream
-    static const bool fused_diag = getenv("SF_FUSED_DIAG") != nullptr;      // tuning aid: one-launch D
     static const int rlazy = getenv("SF_RLAZY") ? atoi(getenv("SF_RLAZY")) : 1;  // tuning aid; measured: no gain for 2, 4, 8
     if (no_lookahead) c = s;
     hipEvent_t e_fork, e_gt_prev = nullptr;
@@ -1104,12 +952,8 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
         }
         // ---- D + F on the side stream (T rows [0, pw) already hold the fully updated diagonal block)
         static const bool leaf_diag = getenv("SF_LEAF_DIAG") != nullptr;  // tuning aid: the 13-launch chain
-        if (!leaf_diag && !fused_diag) {
+        if (!leaf_diag) {
             hipLaunchKernelGGL(k_diag_mfma, dim3(batch), dim3(1024), 0, c, T, sT, pw, info, k0,
-                               rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
-            SF_LAUNCH_CHECK();
-        } else if (fused_diag) {
-            hipLaunchKernelGGL(k_panel_diag, dim3(batch), dim3(256), 0, c, T, sT, pw, info, k0,
                                rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
             SF_LAUNCH_CHECK();
         } else {
