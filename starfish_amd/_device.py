@@ -57,6 +57,35 @@ def workspace(nbytes, dev):
     return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=dev)
 
 
+def band_halfwidth_bound(wave, rows, n_grid, has_global, n_local, n_cheb):
+    """Per-walker upper bound on max|i-j| over the non-zero entries of the structured part of the
+    covariance (global Matern taper r0 = 6 ls, Starfish/models/kernels.py:29; local patches r0 = 4 sigma,
+    kernels.py:73), from host copies of the wavelength grid and of the C-ABI parameter rows
+    (include/starfish_amd.h: [4] log_amp, [5] log_ls, locals after the grid and Chebyshev entries).
+    Conservative: uses the smallest pixel spacing.  Pure host logic (numpy)."""
+    w = np.asarray(wave, dtype=np.float64)
+    rows = np.atleast_2d(np.asarray(rows, dtype=np.float64))
+    big = np.iinfo(np.int32).max
+    if w.size < 2 or not np.all(np.diff(w) > 0):
+        return np.full(rows.shape[0], big, dtype=np.int64)
+    hw = np.zeros(rows.shape[0])
+    if has_global:
+        # metric of the global kernel (kernels.py:27): r = c/2 |wi - wj| / (wi + wj), a quarter of the
+        # velocity separation; r(i, i+d) >= d * dv * (1 - O(r0/c)) (slightly sub-additive)
+        dv = float(np.min(C_KMS / 2 * (w[1:] - w[:-1]) / (w[1:] + w[:-1])))
+        r0 = 6 * np.exp(rows[:, 5])
+        hw = np.maximum(hw, np.floor(r0 / dv * (1 + 4 * r0 / C_KMS + 1e-9)) + 1)
+    off = 6 + n_grid + n_cheb
+    for k in range(n_local):
+        mu = rows[:, off + 3 * k]
+        r0 = 4 * np.exp(rows[:, off + 3 * k + 2])
+        # metric d_i = c/mu |w_i - mu| (kernels.py:69): patch = pixels with d_i <= r0; its extent in
+        # pixels is at most 2 r0 / (smallest step of d), step of d >= (c/mu) * min(diff(w))
+        step = C_KMS / np.abs(mu) * float(np.min(np.diff(w)))
+        hw = np.maximum(hw, np.floor(2 * r0 / step * (1 + 1e-9)) + 1)
+    return np.minimum(hw, big).astype(np.int64)
+
+
 class DeviceOrder:
     """One ``sf_ctx``: the static data of an order + emulator resident in HBM, and the batched calls."""
 
@@ -162,38 +191,9 @@ class DeviceOrder:
         """Largest band half-width (pixels) sf_loglike_banded_batch accepts for this order; -1 = unusable."""
         return int(self.lib.sf_banded_max_halfwidth(self.ctx)) if self.n else -1
 
-    def _spacing(self):
-        """Smallest velocity step between neighbouring pixels in the metric of the global kernel
-        (Starfish/models/kernels.py:27) -- turns a taper radius in km/s into a bound in pixels."""
-        if getattr(self, "_dv_min", None) is None:
-            w = self._keep[0]
-            self._dv_min = float(np.min(C_KMS / 2 * (w[1:] - w[:-1]) / (w[1:] + w[:-1]))) if self.n > 1 else np.inf
-            self._mono = bool(self.n > 1 and np.all(np.diff(w) > 0))
-        return self._dv_min
-
     def halfwidth_bound(self, md, rows):
-        """Per-walker upper bound on max|i-j| over the non-zero entries of the structured part of the
-        covariance (global Matern taper r0 = 6 ls, kernels.py:29; local patches r0 = 4 sigma, kernels.py:73),
-        from the host copy of the parameter rows.  Conservative: uses the smallest pixel spacing."""
-        rows = np.atleast_2d(np.asarray(rows, dtype=np.float64))
-        dv = self._spacing()
-        if not self._mono:
-            return np.full(rows.shape[0], np.iinfo(np.int32).max, dtype=np.int64)
-        w = self._keep[0]
-        hw = np.zeros(rows.shape[0])
-        if md.has_global:
-            r0 = 6 * np.exp(rows[:, 5])
-            # r(i, i+d) >= d * dv * (1 - O(r0/c)): the metric is slightly sub-additive
-            hw = np.maximum(hw, np.floor(r0 / dv * (1 + 4 * r0 / C_KMS + 1e-9)) + 1)
-        off = 6 + self.P + md.n_cheb
-        for k in range(md.n_local):
-            mu = rows[:, off + 3 * k]
-            r0 = 4 * np.exp(rows[:, off + 3 * k + 2])
-            # metric d_i = c/mu |w_i - mu| (kernels.py:69): patch = pixels with d_i <= r0; its extent in
-            # pixels is at most 2 r0 / (smallest step of d), step of d >= (c/mu) * min(diff(w))
-            step = C_KMS / np.abs(mu) * float(np.min(np.diff(w)))
-            hw = np.maximum(hw, np.floor(2 * r0 / step * (1 + 1e-9)) + 1)
-        return np.minimum(hw, np.iinfo(np.int32).max).astype(np.int64)
+        """Per-walker upper bound (pixels) on the support of the structured part of the covariance."""
+        return band_halfwidth_bound(self._keep[0], rows, self.P, bool(md.has_global), int(md.n_local), int(md.n_cheb))
 
     def banded_workspace_bytes(self, md, B, halfwidth):
         return self.lib.sf_banded_workspace_bytes(self.ctx, C.byref(md), int(B), int(halfwidth))

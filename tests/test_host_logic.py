@@ -192,3 +192,32 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle|sf_oracle\s+import|oracle/", text, re.M), \
                     f"{f} reaches into oracle/"
+
+
+def test_band_halfwidth_bound_covers_the_true_support():
+    """Host-side bound used to route walkers to the banded solver: never smaller than the true support of
+    the reference kernels (oracle restatement of models/kernels.py), and tight to a few pixels."""
+    from oracle import sf_oracle as O
+    from starfish_amd._device import band_halfwidth_bound
+
+    rng = np.random.default_rng(11)
+    for n, dv in ((300, 2.0), (257, 3.7)):
+      for jitter in (0.0, 0.2):
+          wave = 5000.0 * np.exp(np.arange(n) * dv / 2.99792458e5)
+          wave[1:-1] += rng.uniform(-jitter, jitter, n - 2) * np.diff(wave).min()  # not exactly log-uniform
+          for ls, sig, mu_i in ((3.0, 6.0, n // 3), (9.0, 2.0, 5), (0.7, 11.0, n - 4)):
+              row = np.zeros(6 + 3 + 2 + 3)
+              row[5] = np.log(ls)
+              row[6 + 3 + 2:] = (wave[mu_i] + 0.01, -8.0, np.log(sig))
+              K = O.matern32_global(wave, 1.0, ls)
+              L = O.gaussian_local(wave, 1.0, wave[mu_i] + 0.01, sig)
+              for has_g, n_loc, M in ((1, 0, K), (0, 1, L), (1, 1, K + L)):
+                  ii, jj = np.nonzero(M)
+                  true_hw = int(np.abs(ii - jj).max())
+                  got = int(band_halfwidth_bound(wave, row, 3, has_g, n_loc, 2)[0])
+                  # always a bound; tight to a few pixels on a regular grid (it uses the smallest spacing)
+                  assert true_hw <= got, (n, ls, sig, has_g, n_loc, true_hw, got)
+                  if jitter == 0 and mu_i == n // 3:  # (a patch cut by the array edge is narrower than the bound)
+                      assert got <= true_hw + 4, (n, ls, sig, has_g, n_loc, true_hw, got)
+    # a grid that is not strictly increasing cannot use the banded solver at all
+    assert band_halfwidth_bound(wave[::-1], row, 3, 1, 1, 2)[0] == np.iinfo(np.int32).max
