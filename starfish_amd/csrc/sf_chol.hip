@@ -64,7 +64,113 @@ struct sf_gemm_args {
     int64_t sY;
     int ldy, mpad, nt128, tm_off, tn_off;
     int mt, nt;
+    int no_syrk;  // tuning aid: diagonal tiles through the generic path
 };
+
+// Diagonal 128 x 128 tile of a symmetric update C -= P P^T (block-diagonal launches): only the 36 MFMA
+// blocks on or below the diagonal are computed, dealt to the 8 waves in equal shares (rows p and 7-p of
+// the 8 x 8 block grid hold 9 blocks; one wave takes 5 of them, its partner 4 plus a spare), and the single
+// operand P is staged once instead of twice.  40 block products per slab instead of 64.
+// Blocks above the diagonal are neither read nor written (nothing references them).
+template <bool RHS, int NTH>
+__device__ __forceinline__ void sf_syrk_diag_tile(const sf_gemm_args& g, int b, int row0, double (*As)[GT * GLD]) {
+    static_assert(NTH == 512, "8 waves");
+    constexpr int NP = 1024 / NTH, RPP = NTH / 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int p = w >> 1, h = w & 1;
+    int bi[5], bj[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        if (h == 0) {
+            bi[q] = 7 - p;
+            bj[q] = q;
+        } else {
+            const int n_hi = 3 - p;  // blocks 5 .. 7-p of row 7-p, then blocks 0 .. p of row p
+            const int qq = q < 4 ? q : 0;
+            bi[q] = qq < n_hi ? 7 - p : p;
+            bj[q] = qq < n_hi ? 5 + qq : qq - n_hi;
+        }
+    }
+    const int nstore = h == 0 ? 5 : 4;
+
+    const int lr = tid >> 3, lc = (tid & 7) * 2;
+    const double* Ap[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) Ap[q] = g.A + (int64_t)b * g.sA + (int64_t)(row0 + lr + RPP * q) * g.lda + lc;
+    double2 ra[NP];
+    const bool do_rhs = RHS && g.rhs;
+    const double* zg = do_rhs ? g.z + (int64_t)b * g.sz + lc : nullptr;
+    double2 zv = make_double2(0.0, 0.0);
+    double part[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) part[q] = 0.0;
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) ra[q] = *(const double2*)(Ap[q] + kt * GK);
+        if (RHS && do_rhs) zv = *(const double2*)(zg + kt * GK);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            double* pa = &As[buf][(lr + RPP * q) * GLD + lc];
+            pa[0] = ra[q].x;
+            pa[1] = ra[q].y;
+        }
+        if (RHS && do_rhs) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) part[q] += ra[q].x * zv.x + ra[q].y * zv.y;
+        }
+    };
+    const int nk = g.K / GK;
+    if (nk > 0) gload(0);
+    sf_d4 acc[5];
+    const double* Cin = g.Cin + (int64_t)b * g.sCin + (int64_t)row0 * g.ldcin + row0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[q][r] = Cin[(int64_t)(16 * bi[q] + lq + 4 * r) * g.ldcin + 16 * bj[q] + l15];
+    if (nk > 0) lstore(0);
+    __syncthreads();
+    auto compute = [&](int cur) {
+        const double* S = &As[cur][l15 * GLD + lq];
+#pragma unroll
+        for (int ks = 0; ks < GK / 4; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[bi[q] * 16 * GLD + ks * 4], S[bj[q] * 16 * GLD + ks * 4],
+                                                              acc[q], 0, 0, 0);
+        }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        gload(kt + 1);
+        compute(kt & 1);
+        lstore((kt & 1) ^ 1);
+        __syncthreads();
+    }
+    if (nk > 0) compute((nk - 1) & 1);
+    double* Cout = g.Cout + (int64_t)b * g.sCout + (int64_t)row0 * g.ldcout + row0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        if (q >= nstore) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Cout[(int64_t)(16 * bi[q] + lq + 4 * r) * g.ldcout + 16 * bj[q] + l15] = acc[q][r];
+    }
+    if (RHS && do_rhs) {
+        double* rhs = g.rhs + (int64_t)b * g.srhs + row0;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            double v = part[q];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            if ((tid & 7) == 0) rhs[lr + RPP * q] -= v;
+        }
+    }
+}
 
 // Occupancy note (measured on MI355X, tools/probes/mfma_clock.hip): ONE wave issues a
 // v_mfma_f64_16x16x4_f64 only every ~140 cycles even with independent accumulators, two waves per
@@ -103,6 +209,10 @@ __global__ __launch_bounds__(NTH, (NTH == 256) ? 2 : NTH / 128) void k_gemm_nt(s
         if (g.Cin) g.Cin += jb * g.dC;
         g.Cout += jb * g.dC;
         if (RHS && g.rhs) g.rhs += jb * SF_NB;
+        if (NTH == 512 && NEG && tm == tn && rows_here == GT && g.K > 0 && g.A == g.B && g.Cin && !g.no_syrk) {
+            sf_syrk_diag_tile<RHS, 512>(g, b, tm * GT, As);
+            return;
+        }
     } else {
         tm = t / g.nt;
         tn = t - tm * g.nt;
@@ -480,6 +590,8 @@ static int launch_gemm(sf_gemm_args g, int batch, bool neg, double flops, hipStr
         sf_set_error("gemm grid too large");
         return SF_EINVAL;
     }
+    static const bool no_syrk = getenv("SF_NO_SYRK") != nullptr;
+    g.no_syrk = no_syrk;
     void* tok;
     sf_prof_gemm_begin(s, flops, &tok);
     static const bool big = getenv("SF_GEMM_1024") != nullptr;  // tuning aid: 16 waves of 32 x 32
