@@ -529,7 +529,7 @@ struct Carve {
     }
 };
 struct Work {
-    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *ybro, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf, *mult;
+    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *ybro, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf, *mult, *gtab;
     double2* fft;
     int *info_e, *info_c;
     unsigned char* tilemap;
@@ -559,6 +559,7 @@ static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, siz
     w.ztrsv = k.take<double>(b * c->npad);
     w.ltbuf = need_C ? k.take<double>(sf_potrf_work_doubles(c->npad, B)) : nullptr;  // Cholesky scratch
     w.tilemap = need_C ? k.take<unsigned char>(b * (size_t)(c->npad / 128 + 1) * (c->npad / 128 + 1)) : nullptr;
+    w.gtab = need_C ? k.take<double>(b * (size_t)c->npad) : nullptr;
     w.C = need_C ? k.take<double>(b * (size_t)c->npad * c->lda) : nullptr;
     w.bytes = sf_align_up(k.off, 256);
     return w;
@@ -712,6 +713,7 @@ static sf_fill_args fill_args(sf_ctx* c, const sf_model_desc* mdl, const double*
     f.loguniform = c->loguniform;
     f.tilemap = nullptr;
     f.nt128 = 0;
+    f.gtab = nullptr;
     return f;
 }
 
@@ -807,6 +809,7 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
         f.stride = stride;
         f.lower_only = 1;
         f.add_jitter = 1;
+        f.gtab = w.gtab;        // per-diagonal table of the global kernel (used on log-uniform grids only)
         f.tilemap = w.tilemap;  // only tiles that carry more than the rank-m term are materialised
         f.nt128 = (c->npad + 127) / 128;
         rc = sf_launch_fill(f, B, s);

@@ -75,6 +75,7 @@ struct sf_fill_args {
     int loguniform;        // wave_i = wave_0 e^(i delta) to rounding -> K_global depends on i-j only
     unsigned char* tilemap; // optional [B][nt128*nt128]: 1 = the 128x128 tile is materialised in C
     int nt128;
+    double* gtab;          // optional [B][n] scratch: K_global per diagonal (log-uniform grids, likelihood path)
 };
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);
 // band storage of the structured part of C (sf_band.hip consumes it); a.npad = rows written (>= a.n)

@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256, 4) void k_fill_plain(sf_fill_args a, int nt, i
     }
 }
 
+__global__ void k_band_gtab(sf_fill_args a, double* __restrict__ gtab, int ws);
+
 // Pass 2 (only sub-tiles that intersect the support of a structured kernel, everything else exits at
 // once): C += K_global, then C += (0 + K_local,0 + K_local,1 ...), then the jitter -- the reference's
 // order of additions (spectrum_model.py:348, 353-363, 399).
@@ -242,8 +244,13 @@ __global__ __launch_bounds__(256) void k_fill_band(sf_fill_args a, int nt) {
             }
             double w_col[4];
             for (int r = 0; r < 4; ++r) w_col[r] = (col0 + r < a.n) ? a.wave[col0 + r] : 1.0;
-            if (do_glob)
+            if (do_glob && a.gtab) {  // log-uniform grid: one value per diagonal (see k_band_gtab)
+                const double* gt = a.gtab + (int64_t)b * a.n;
+                for (int r = 0; r < 4; ++r)
+                    if (col0 + r < a.n) v[r] = v[r] + gt[abs(row - (col0 + r))];
+            } else if (do_glob) {
                 for (int r = 0; r < 4; ++r) v[r] = v[r] + sf_matern_elem(w_row, w_col[r], g_amp, g_ls, g_r0);
+            }
             if (lmask) {
                 double loc[4] = {0.0, 0.0, 0.0, 0.0};
                 for (int k = 0; k < a.n_local; ++k) {
@@ -288,10 +295,16 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
         SF_LAUNCH_CHECK();
     }
     const int structured = a.has_global || a.n_local > 0;
+    sf_fill_args a2 = a;
+    if (!(a.gtab && a.has_global && a.loguniform && a.lower_only)) a2.gtab = nullptr;
+    if (a2.gtab) {
+        hipLaunchKernelGGL(k_band_gtab, dim3((a.n + 255) / 256, B), dim3(256), 0, s, a, a2.gtab, a.n - 1);
+        SF_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_fill_plain, dim3((unsigned)nblk), dim3(256), 0, s, a, nt, structured ? 0 : 1);
     SF_LAUNCH_CHECK();
     if (structured) {
-        hipLaunchKernelGGL(k_fill_band, dim3((unsigned)nblk), dim3(256), 0, s, a, nt);
+        hipLaunchKernelGGL(k_fill_band, dim3((unsigned)nblk), dim3(256), 0, s, a2, nt);
         SF_LAUNCH_CHECK();
     }
     return SF_OK;
