@@ -222,9 +222,12 @@ int sf_loglike_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const doubl
  * max |i-j| over the non-zero entries of Bd (in pixels, over the whole batch); walkers whose
  * support is wider get info = SF_INFO_BANDWIDTH and lnl = -inf and must be re-run through
  * sf_loglike_batch.  Requires a strictly increasing wavelength grid and
- * halfwidth <= sf_banded_max_halfwidth(ctx).  Results agree with the dense path to rounding
- * (different summation order), not bit for bit. */
+ * halfwidth <= sf_banded_max_halfwidth(ctx).  Up to sf_banded_window_halfwidth(ctx) (144 px for
+ * m <= 15) the band is swept through an LDS-resident window; wider bands are factorised in place in
+ * HBM/L2 by a left-looking kernel (cost grows with halfwidth^2: group walkers by width).  Results
+ * agree with the dense path to rounding (different summation order), not bit for bit. */
 int sf_banded_max_halfwidth(const sf_ctx* ctx);
+int sf_banded_window_halfwidth(const sf_ctx* ctx);
 size_t sf_banded_workspace_bytes(const sf_ctx* ctx, const sf_model_desc* model, int B, int halfwidth);
 int sf_loglike_banded_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const double* d_params,
                             int halfwidth, double* d_lnl, double* d_logdet, double* d_sqmah,

@@ -187,6 +187,10 @@ class DeviceOrder:
         self._ws = None
 
     # ------------------------------------------------------------------ structure-exploiting solver
+    def banded_window_halfwidth(self):
+        """Half-widths up to this value use the LDS-window sweep; wider ones the in-place HBM/L2 kernel."""
+        return int(self.lib.sf_banded_window_halfwidth(self.ctx)) if self.n else -1
+
     def banded_max_halfwidth(self):
         """Largest band half-width (pixels) sf_loglike_banded_batch accepts for this order; -1 = unusable."""
         return int(self.lib.sf_banded_max_halfwidth(self.ctx)) if self.n else -1
@@ -278,8 +282,12 @@ class DeviceOrder:
         )
         if want_resid:
             out["resid"] = np.full((B, self.n), np.nan)
-        idx = np.nonzero(fits)[0]
-        if idx.size:
+        # two groups: the cost of the wide-band kernel grows with the square of the half-width, so the
+        # walkers that fit the LDS window are not dragged along with the wide ones
+        wwin = self.banded_window_halfwidth()
+        for idx in (np.nonzero(fits & (hw <= wwin))[0], np.nonzero(fits & (hw > wwin))[0]):
+            if not idx.size:
+                continue
             W = int(hw[idx].max())
             with torch.cuda.device(self.dev):
                 P = to_dev(rows[idx], self.dev)

@@ -110,6 +110,7 @@ SIGNATURES = {
         [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
     ),
     "sf_banded_max_halfwidth": (C.c_int, [_VP]),
+    "sf_banded_window_halfwidth": (C.c_int, [_VP]),
     "sf_banded_workspace_bytes": (C.c_size_t, [_VP, C.POINTER(ModelDesc), C.c_int, C.c_int]),
     "sf_loglike_banded_batch": (
         C.c_int,

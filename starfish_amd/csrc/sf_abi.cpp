@@ -850,16 +850,24 @@ static BandWork carve_band(const sf_ctx* c, const sf_model_desc* mdl, int B, int
     Carve k(p, cap);
     k.off = base_bytes;
     BandWork w;
-    w.ldb = (halfwidth + 2) & ~1;
+    const bool wide = halfwidth > sf_band_max_halfwidth(c->m + 1);
+    w.ldb = wide ? sf_band_wide_storage_width(halfwidth) : ((halfwidth + 2) & ~1);
     w.band = k.take<double>((size_t)B * c->npad * w.ldb);
     w.gram = k.take<double>((size_t)B * (c->m + 1) * (c->m + 1));
     w.logdet_band = k.take<double>((size_t)B);
-    w.twist = k.take<double>(sf_band_twisted_work_doubles(halfwidth, c->m + 1, B));
-    w.gtab = k.take<double>((size_t)B * (halfwidth + 2));
+    w.twist = wide ? k.take<double>(sf_band_wide_work_doubles((c->n + 15) / 16 * 16, c->m + 1, B))
+                   : k.take<double>(sf_band_twisted_work_doubles(halfwidth, c->m + 1, B));
+    w.gtab = k.take<double>((size_t)B * (w.ldb + 2));
     w.bytes = sf_align_up(k.off, 256);
     return w;
 }
 extern "C" int sf_banded_max_halfwidth(const sf_ctx* c) {
+    if (!c || !c->n) return SF_EINVAL;
+    if (!c->monotonic) return -1;
+    const int lds_max = sf_band_max_halfwidth(c->m + 1), wide_max = sf_band_wide_max_halfwidth();
+    return c->m + 1 <= 48 ? (wide_max > lds_max ? wide_max : lds_max) : lds_max;
+}
+extern "C" int sf_banded_window_halfwidth(const sf_ctx* c) {
     if (!c || !c->n) return SF_EINVAL;
     return c->monotonic ? sf_band_max_halfwidth(c->m + 1) : -1;
 }
@@ -909,13 +917,17 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         f.lower_only = 1;
         f.add_jitter = 1;
         f.npad = (c->n + 15) / 16 * 16;
-        rc = sf_launch_band_fill(f, B, bw.band, halfwidth + 1, bw.ldb, sband, w.info_c, bw.gtab, s);
+        const bool wide = halfwidth > sf_band_max_halfwidth(c->m + 1);
+        rc = sf_launch_band_fill(f, B, bw.band, wide ? bw.ldb : halfwidth + 1, bw.ldb, sband, w.info_c, bw.gtab, s);
         if (rc) return rc;
     }
     {
         ProfScope ps(s, PS_POTRF);
         const int n16 = (c->n + 15) / 16 * 16;
-        if (sf_band_twisted_applicable(n16, halfwidth, B))
+        if (halfwidth > sf_band_max_halfwidth(c->m + 1))
+            rc = sf_launch_band_wide(bw.band, n16, halfwidth, bw.ldb, sband, B, w.resid, c->npad, w.Y, c->m + 1,
+                                     c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band, bw.gram, w.info_c, bw.twist, s);
+        else if (sf_band_twisted_applicable(n16, halfwidth, B))
             rc = sf_launch_band_forms_twisted(bw.band, n16, halfwidth, bw.ldb, sband, B, w.resid, c->npad, w.Y,
                                               c->m + 1, c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band,
                                               bw.gram, w.info_c, bw.twist, s);

@@ -227,3 +227,49 @@ def test_banded_cfg5_and_wasp14_vs_reference():
     out = do.loglike(md, rows, solver="auto")
     assert out["info"][0] == 0
     assert close_lnl(out["lnl"][0], g["lnl"][0])
+
+
+@pytest.mark.parametrize("ls", [14.0, 25.0, 60.0])
+def test_wide_band_kernel_matches_dense_and_oracle(ls):
+    """Length scales beyond the LDS window (W = 24 ls/dv > 144 px) go through the in-place left-looking
+    band kernel: same value as the dense path and the oracle."""
+    o = synth.make_order(N=1024)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    plist = [synth.vector_to_oracle_params(p) for p in synth.walker_ball(o, B=6)]
+    for p in plist:
+        p["global_cov"] = (p["global_cov"][0], float(np.log(ls)) + 0.01 * (p["vz"] - 10.0))
+    md, rows = pack_rows(do, plist)
+    hw = do.halfwidth_bound(md, rows)
+    assert (hw > do.banded_window_halfwidth()).all() and (hw <= do.banded_max_halfwidth()).all()
+    band = do.loglike(md, rows, solver="banded", want_resid=True)
+    dense = do.loglike(md, rows, want_resid=True)
+    assert (band["info"] == 0).all()
+    np.testing.assert_allclose(band["lnl"], dense["lnl"], rtol=1e-10)
+    np.testing.assert_allclose(band["logdet"], dense["logdet"], rtol=1e-11)
+    np.testing.assert_allclose(band["sqmah"], dense["sqmah"], rtol=1e-8)
+    np.testing.assert_array_equal(band["resid"], dense["resid"])
+    for b in (0, 5):
+        assert close_lnl(band["lnl"][b], O.log_likelihood(oo, plist[b]))
+    # mixed widths in one call: narrow walkers use the window sweep, wide ones this kernel, absurdly wide -> dense
+    mixed = [dict(plist[0], global_cov=(plist[0]["global_cov"][0], np.log(5.0))), plist[1],
+             dict(plist[2], global_cov=(plist[2]["global_cov"][0], np.log(900.0)))]
+    md, rows = pack_rows(do, mixed)
+    auto = do.loglike(md, rows, solver="auto")
+    ref = do.loglike(md, rows)
+    assert (auto["info"] == 0).all()
+    np.testing.assert_allclose(auto["lnl"], ref["lnl"], rtol=1e-10)
+
+
+def test_wide_band_full_size_cfg2_shape():
+    o = synth.make_order(N=4096)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    plist = [synth.vector_to_oracle_params(p) for p in synth.walker_ball(o, B=4)]
+    for p in plist:
+        p["global_cov"] = (p["global_cov"][0], float(np.log(30.0)))
+    md, rows = pack_rows(do, plist)
+    band = do.loglike(md, rows, solver="banded")
+    dense = do.loglike(md, rows)
+    assert (band["info"] == 0).all()
+    np.testing.assert_allclose(band["lnl"], dense["lnl"], rtol=1e-10)
