@@ -273,3 +273,31 @@ def test_wide_band_full_size_cfg2_shape():
     dense = do.loglike(md, rows)
     assert (band["info"] == 0).all()
     np.testing.assert_allclose(band["lnl"], dense["lnl"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("N", [1000, 3000])
+def test_auto_solver_fuzz_ragged_sizes(N):
+    """Random hyper-parameters (supports from a few pixels to wider than any banded kernel), sizes that are not
+    multiples of 16: solver="auto" agrees with the dense factorisation walker by walker."""
+    rng = np.random.default_rng(N)
+    o = synth.make_order(N=N)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    plist = [synth.vector_to_oracle_params(p) for p in synth.walker_ball(o, B=24, seed=3)]
+    for i, p in enumerate(plist):
+        ls = float(np.exp(rng.uniform(np.log(0.3), np.log(70.0))))
+        sig = float(np.exp(rng.uniform(np.log(1.0), np.log(40.0))))
+        mu = float(rng.uniform(oo.wave[0] - 1.0, oo.wave[-1] + 1.0))  # patches may hang over either edge
+        p["global_cov"] = (p["global_cov"][0] + rng.uniform(-1, 1), np.log(ls))
+        p["local_cov"] = [(mu, p["local_cov"][0][1] + rng.uniform(-1, 1), np.log(sig))]
+    md, rows = pack_rows(do, plist)
+    hw = do.halfwidth_bound(md, rows)
+    assert (hw <= do.banded_window_halfwidth()).any() and (hw > do.banded_window_halfwidth()).any()
+    auto = do.loglike(md, rows, solver="auto")
+    dense = do.loglike(md, rows)
+    assert (auto["info"] == 0).all() and (dense["info"] == 0).all()
+    np.testing.assert_allclose(auto["lnl"], dense["lnl"], rtol=1e-10)
+    np.testing.assert_allclose(auto["logdet"], dense["logdet"], rtol=1e-11)
+    np.testing.assert_allclose(auto["sqmah"], dense["sqmah"], rtol=1e-8)
+    b = int(np.argmax(hw))
+    assert close_lnl(auto["lnl"][b], O.log_likelihood(oo, plist[b]))
