@@ -186,6 +186,50 @@ class Emulator:
             self._factor_interpolator = LinearNDInterpolator(self.grid_points, self.factors, rescale=True)
         return self._factor_interpolator(np.asarray(params))
 
+    def load_flux(self, params, norm=False):
+        """One random realisation of the emulated spectrum at ``params``: weights drawn from the GP
+        conditional, reconstructed through the eigenspectra (Starfish/emulator/emulator.py:404-427).
+        The random draw is numpy's (host), as in the reference; mean and covariance come from the device."""
+        P = np.atleast_2d(np.asarray(params, dtype=np.float64))
+        fluxes = np.empty((P.shape[0], self.eigenspectra.shape[-1]))
+        X = self.eigenspectra * self.flux_std
+        for i, p in enumerate(P):
+            mu, cov = self(p)
+            fluxes[i] = np.random.multivariate_normal(mu, cov) @ X + self.flux_mean
+        if norm:
+            fluxes *= np.atleast_1d(self.norm_factor(P))[:, np.newaxis]
+        return np.squeeze(fluxes)
+
+    def determine_chunk_log(self, wavelength, buffer=50):
+        """Truncate ``wl`` / ``eigenspectra`` to the shortest power-of-two-length window of the emulator grid
+        that still covers ``wavelength`` +- ``buffer`` Angstrom (Starfish/emulator/emulator.py:446-482;
+        the window selection follows Starfish/grid_tools/utils.py:181-240)."""
+        wavelength = np.asarray(wavelength, dtype=np.float64)
+        wl_min, wl_max = wavelength.min() - buffer, wavelength.max() + buffer
+        wl = self.wl
+        if wl_min < wl.min() or wl_max > wl.max():
+            raise AssertionError(
+                f"determine_chunk_log: wl_min {wl_min:.2f} and wl_max {wl_max:.2f} are not within the bounds "
+                f"of the grid {wl.min():.2f} to {wl.max():.2f}."
+            )
+        inside = np.nonzero((wl >= wl_min) & (wl <= wl_max))[0]
+        chunk = len(wl)
+        while chunk // 2 > inside.size:
+            chunk //= 2
+        if chunk < len(wl):
+            centre = (inside[0] + inside[-1]) // 2
+            lo = min(max(centre - chunk // 2, 0), len(wl) - chunk)
+            # the window must contain the requested range; slide it if the centring cut an end off
+            lo = min(lo, inside[0])
+            lo = max(lo, inside[-1] + 1 - chunk)
+            sel = slice(lo, lo + chunk)
+            self.wl = wl[sel]
+            self.eigenspectra = self.eigenspectra[:, sel]
+            self.flux_mean = self.flux_mean[sel]
+            self.flux_std = self.flux_std[sel]
+            self._device = None  # static device data is rebuilt on the next query
+        assert self.wl.min() <= wl_min and self.wl.max() >= wl_max
+
     def get_index(self, params):
         params = np.atleast_2d(params)
         marks = np.abs(self.grid_points - np.expand_dims(params, 1)).sum(axis=-1)

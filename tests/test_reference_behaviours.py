@@ -1,0 +1,306 @@
+"""Behavioural checks in the style of the reference's own unit tests for the functions on the path
+(tests/test_transforms.py, tests/test_emulator/test_emulator.py, tests/test_spectrum.py of Starfish v0.4.2),
+re-stated on synthetic data: argument errors, identity cases, shapes with stacked fluxes, round trips.
+The numbers themselves are pinned elsewhere (golden vectors); this file pins the API behaviour a Starfish
+user relies on.  Host-only functions run in the CPU suite, device-backed ones are marked gpu."""
+import numpy as np
+import pytest
+
+from starfish_amd import Spectrum, synth
+from starfish_amd.emulator import Emulator
+from starfish_amd.transforms import (
+    chebyshev_correct,
+    doppler_shift,
+    extinct,
+    instrumental_broaden,
+    renorm,
+    rescale,
+    resample,
+    rotational_broaden,
+)
+from starfish_amd.utils import calculate_dv, create_log_lam_grid
+
+
+@pytest.fixture(scope="module")
+def mock_data():
+    rng = np.random.default_rng(7)
+    wave = 5000.0 * np.exp(np.arange(2048) * 2.0 / 2.99792458e5)
+    flux = 1.0 + 0.1 * np.sin(wave / 7.0) + 0.01 * rng.standard_normal(wave.size)
+    return wave, flux
+
+
+def make_emulator(trained=True):
+    o = synth.make_order(N=256, m=4, seed=5)
+    emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"], o["w_hat"],
+                   o["flux_mean"], o["flux_std"], o["factors"])
+    emu._trained = trained
+    return emu
+
+
+# ------------------------------------------------------------------------------- host-only
+class TestDopplerShift:
+    def test_no_change(self, mock_data):
+        assert np.allclose(doppler_shift(mock_data[0], 0), mock_data[0])
+
+    def test_blueshift_and_redshift(self, mock_data):
+        assert np.all(doppler_shift(mock_data[0], -1e3) < mock_data[0])
+        assert np.all(doppler_shift(mock_data[0], 1e3) > mock_data[0])
+
+    def test_round_trip(self, mock_data):
+        assert np.allclose(doppler_shift(doppler_shift(mock_data[0], 1e3), -1e3), mock_data[0])
+
+
+class TestRescale:
+    @pytest.mark.parametrize("log_scale", [1, 2, 3, -124, -42.2, 0.5])
+    def test_transform(self, mock_data, log_scale):
+        scale = np.exp(log_scale)
+        assert np.allclose(rescale(mock_data[1], scale), mock_data[1] * scale)
+
+    def test_identity_and_round_trip(self, mock_data):
+        assert np.allclose(rescale(mock_data[1], 1), mock_data[1])
+        assert np.allclose(rescale(rescale(mock_data[1], 0.01), 100), mock_data[1])
+
+    def test_many_fluxes(self, mock_data):
+        stack = np.tile(mock_data[1], (4, 1))
+        out = rescale(stack, 2)
+        assert out.shape == stack.shape and not np.allclose(out, stack)
+
+
+class TestRenorm:
+    def test_transform(self, mock_data):
+        wave, flux = mock_data
+        ref = rescale(flux, 70)
+        out = renorm(wave, flux, ref)
+        assert out.shape == flux.shape
+        assert np.allclose(out, flux * 70) and np.allclose(out, ref)
+
+    def test_identity_and_round_trip(self, mock_data):
+        wave, flux = mock_data
+        assert np.allclose(renorm(wave, flux, flux), flux)
+        assert np.allclose(renorm(wave, renorm(wave, flux, rescale(flux, 70)), flux), flux)
+
+    def test_many_fluxes(self, mock_data):
+        wave, flux = mock_data
+        stack = np.tile(flux, (4, 1))
+        out = renorm(wave, stack, rescale(flux, 70))
+        assert out.shape == stack.shape and np.allclose(out, stack * 70)
+
+
+class TestSpectrumContainers:
+    def test_defaults(self, mock_data):
+        wave, flux = mock_data
+        spec = Spectrum(wave, flux)
+        assert len(spec) == 1 and spec.shape == (1, wave.size)
+        assert np.all(spec.sigmas == 1.0) and np.all(spec.masks)
+
+    def test_masking(self, mock_data):
+        wave, flux = mock_data
+        mask = np.ones_like(wave, dtype=bool)
+        mask[:100] = False
+        spec = Spectrum(wave, flux, masks=mask)
+        assert spec[0].wave.size == wave.size - 100
+        assert np.array_equal(spec[0].flux, flux[100:])
+
+    def test_reshaping_and_iteration(self):
+        waves = [np.linspace(1e4, 2e4, 100), np.linspace(2e4, 3e4, 100)]
+        fluxes = [np.sin(waves[0]), np.cos(waves[1])]
+        data = Spectrum(np.hstack(waves), np.hstack(fluxes), name="single")
+        assert data.shape == (1, 200)
+        reshaped = data.reshape((2, -1))
+        assert reshaped.shape == (2, 100) and reshaped.name == "single"
+        assert np.allclose(reshaped.waves, waves) and np.allclose(reshaped.fluxes, fluxes)
+        data.shape = (2, -1)
+        assert np.allclose(reshaped.waves, data.waves) and np.allclose(reshaped.fluxes, data.fluxes)
+        assert len(list(iter(reshaped))) == 2 and str(reshaped).startswith("single")
+        for i, order in enumerate(reshaped):
+            assert order == reshaped[i]
+        reshaped[0], reshaped[1] = reshaped[1], reshaped[0]
+
+    def test_set_ragged_length(self, mock_data):
+        wave, flux = mock_data
+        spec = Spectrum(wave, flux)
+        with pytest.raises(ValueError):
+            spec[0] = spec.reshape((2, -1))[0]
+
+
+class TestLogLambdaGrid:
+    @pytest.mark.parametrize("dv", [0.5, 2.0, 10.0])
+    def test_grid_dv_not_larger_than_requested(self, dv):
+        grid = create_log_lam_grid(dv, 3000, 13000)
+        assert calculate_dv(grid["wl"]) <= dv
+        assert {"wl", "CRVAL1", "CDELT1", "NAXIS1"} <= set(grid)
+        assert grid["NAXIS1"] == len(grid["wl"]) and (len(grid["wl"]) & (len(grid["wl"]) - 1)) == 0
+
+    @pytest.mark.parametrize("start,end", [(3000, 2000), (-1, 5000), (5000, 0)])
+    def test_invalid_points(self, start, end):
+        with pytest.raises(ValueError):
+            create_log_lam_grid(2.0, start, end)
+
+
+# ------------------------------------------------------------------------------- device-backed
+@pytest.mark.gpu
+class TestInstrumentalBroaden:
+    @pytest.mark.parametrize("fwhm", [-20, -1.00, -np.finfo(np.float64).tiny])
+    def test_bad_fwhm(self, mock_data, fwhm):
+        with pytest.raises(ValueError):
+            instrumental_broaden(*mock_data, fwhm)
+
+    def test_0_fwhm_is_identity(self, mock_data):
+        np.testing.assert_allclose(instrumental_broaden(*mock_data, 0), mock_data[1], rtol=0, atol=1e-12)
+
+    def test_broadens_and_keeps_shape_of_stacks(self, mock_data):
+        assert not np.allclose(instrumental_broaden(*mock_data, 400), mock_data[1])
+        stack = np.tile(mock_data[1], (4, 1))
+        out = instrumental_broaden(mock_data[0], stack, 400)
+        assert out.shape == stack.shape and not np.allclose(out, stack)
+        np.testing.assert_array_equal(out[0], out[3])
+
+
+@pytest.mark.gpu
+class TestRotationalBroaden:
+    @pytest.mark.parametrize("vsini", [-20, -1.00, -np.finfo(np.float64).eps, 0])
+    def test_bad_vsini(self, mock_data, vsini):
+        with pytest.raises(ValueError):
+            rotational_broaden(*mock_data, vsini)
+
+    def test_broadens_and_keeps_shape_of_stacks(self, mock_data):
+        assert not np.allclose(rotational_broaden(*mock_data, 84), mock_data[1])
+        stack = np.tile(mock_data[1], (4, 1))
+        out = rotational_broaden(mock_data[0], stack, 400)
+        assert out.shape == stack.shape and not np.allclose(out, stack)
+
+    def test_flux_is_conserved(self, mock_data):
+        # both kernels are normalised (multiplier 1 at zero frequency): the mean level survives
+        out = rotational_broaden(*mock_data, 30)
+        assert abs(out.mean() - mock_data[1].mean()) < 1e-12
+
+
+@pytest.mark.gpu
+class TestResample:
+    @pytest.mark.parametrize("wave", [np.linspace(-1, -0.5), np.linspace(0, 1e4)])
+    def test_bad_waves(self, mock_data, wave):
+        with pytest.raises(ValueError):
+            resample(*mock_data, wave)
+
+    def test_shapes(self, mock_data):
+        dv = calculate_dv(mock_data[0])
+        new_wave = create_log_lam_grid(dv, mock_data[0].min(), mock_data[0].max())["wl"]
+        new_wave = new_wave[(new_wave >= mock_data[0].min()) & (new_wave <= mock_data[0].max())]
+        assert resample(*mock_data, new_wave).shape == new_wave.shape
+        stack = np.tile(mock_data[1], (4, 1))
+        assert resample(mock_data[0], stack, new_wave).shape == (4, len(new_wave))
+
+    def test_interpolates_the_knots(self, mock_data):
+        np.testing.assert_allclose(resample(*mock_data, mock_data[0][5:-5]), mock_data[1][5:-5], rtol=0, atol=1e-11)
+
+
+@pytest.mark.gpu
+class TestChebyshevCorrection:
+    @pytest.mark.parametrize("coeffs", [[1, 0.005, 0.003, 0], [1, -0.005, 0.0, -0.9], [1, 0, 0.88, 1.2]])
+    def test_transforms(self, mock_data, coeffs):
+        assert not np.allclose(chebyshev_correct(*mock_data, coeffs), mock_data[1])
+
+    def test_no_change(self, mock_data):
+        assert np.allclose(chebyshev_correct(*mock_data, [1, 0, 0, 0]), mock_data[1])
+
+    def test_c0_must_be_one(self, mock_data):
+        with pytest.raises(ValueError):
+            chebyshev_correct(*mock_data, [0.9, 0, 0, 0])
+
+
+@pytest.mark.gpu
+class TestExtinct:
+    @pytest.mark.parametrize("Av,Rv", [(0.4, 2), (0.6, 3.2), (1, 4), (1.2, 5)])
+    def test_extinct(self, mock_data, Av, Rv):
+        out = extinct(*mock_data, Av=Av, Rv=Rv, law="ccm89")
+        assert not np.allclose(out, mock_data[1]) and np.all(out < mock_data[1])
+
+    def test_no_extinct(self, mock_data):
+        assert np.allclose(extinct(*mock_data, 0, 3.1, "ccm89"), mock_data[1])
+
+    def test_bad_laws(self, mock_data):
+        with pytest.raises(ValueError):
+            extinct(*mock_data, 1.0, 2.2, law="hello")
+
+    @pytest.mark.parametrize("Av,Rv", [(0.2, -1), (0.3, -np.finfo(np.float64).tiny)])
+    def test_bad_av_rv(self, mock_data, Av, Rv):
+        with pytest.raises(ValueError):
+            extinct(*mock_data, law="ccm89", Av=Av, Rv=Rv)
+
+    def test_many_fluxes(self, mock_data):
+        stack = np.tile(mock_data[1], (4, 1))
+        out = extinct(mock_data[0], stack, 0.3)
+        assert out.shape == stack.shape and not np.allclose(out, stack)
+
+
+@pytest.mark.gpu
+class TestEmulator:
+    def test_call(self):
+        emu = make_emulator()
+        mu, cov = emu([6020, 4.21, -0.01])
+        assert mu.shape == (emu.ncomps,) and cov.shape == (emu.ncomps, emu.ncomps)
+        np.testing.assert_allclose(cov, cov.T, rtol=0, atol=1e-12 * np.abs(cov).max())
+
+    def test_std_and_batch(self):
+        emu = make_emulator()
+        params = [[6020, 4.21, -0.01], [6104, 4.01, -0.23], [6054, 4.15, -0.16]]
+        mu, var = emu(params[0], full_cov=False)
+        assert mu.shape == (emu.ncomps,) and var.shape == (emu.ncomps,)
+        with pytest.raises(ValueError):
+            emu(params, full_cov=True, reinterpret_batch=True)
+        mus, vars_ = emu(params, full_cov=False, reinterpret_batch=True)
+        for i, p in enumerate(params):
+            m_i, v_i = emu(p, full_cov=False, reinterpret_batch=True)
+            assert np.allclose(mus[i], m_i) and np.allclose(vars_[i], v_i)
+
+    def test_warns_before_trained(self):
+        with pytest.warns(UserWarning):
+            make_emulator(trained=False)([6000, 4.2, 0.0])
+
+    def test_out_of_range_raises(self):
+        with pytest.raises(ValueError):
+            make_emulator()([5000, 4.2, 0.0])
+
+    def test_load_flux(self):
+        emu = make_emulator()
+        flux = emu.load_flux([6020, 4.21, -0.01])
+        assert flux.shape == (emu.eigenspectra.shape[-1],) and np.all(np.isfinite(flux))
+        params = [[6020, 4.21, -0.01], [6104, 4.01, -0.23]]
+        fluxes = emu.load_flux(params)
+        assert len(fluxes) == len(params) and np.all(np.isfinite(fluxes))
+        np.random.seed(123)
+        normed = emu.load_flux(params, norm=True)
+        np.random.seed(123)
+        raw = emu.load_flux(params)
+        assert np.allclose(emu.norm_factor(params)[:, np.newaxis] * raw, normed)
+
+    def test_hyper_parameter_vector_and_dict(self):
+        emu = make_emulator()
+        P0 = emu.get_param_vector()
+        P0[0] = 1.0
+        emu.set_param_vector(P0)
+        assert np.allclose(emu.get_param_vector(), P0)
+        d = emu.get_param_dict()
+        d["log_lambda_xi"] = 1.0
+        emu.set_param_dict(d)
+        assert emu.get_param_dict() == d and emu["log_lambda_xi"] == 1.0
+        assert "log_variance:0" in emu.hyperparams and "log_lengthscale:0:0" in emu.hyperparams
+
+    def test_bulk_flux_str_and_index(self):
+        emu = make_emulator()
+        assert emu.bulk_fluxes.shape == (emu.ncomps + 2, emu.eigenspectra.shape[-1])
+        assert str(emu).startswith("Emulator")
+        assert emu.get_index(emu.grid_points[4]) == 4
+        assert np.isfinite(emu.log_likelihood())
+
+    def test_determine_chunk_log(self):
+        emu = make_emulator()
+        n0 = emu.wl.size
+        lo, hi = emu.wl[n0 // 2 - 40], emu.wl[n0 // 2 + 40]
+        emu.determine_chunk_log([lo, hi], buffer=1.0)
+        n1 = emu.wl.size
+        assert n1 < n0 and (n1 & (n1 - 1)) == 0
+        assert emu.wl.min() <= lo - 1.0 and emu.wl.max() >= hi + 1.0
+        assert emu.eigenspectra.shape[-1] == n1 and emu.bulk_fluxes.shape == (emu.ncomps + 2, n1)
+        mu, cov = emu([6020, 4.21, -0.01])  # still usable after the truncation
+        assert mu.shape == (emu.ncomps,)
