@@ -191,6 +191,12 @@ int sf_emulator_query_batch(sf_ctx* ctx, const sf_model_desc* model, int B,
                             const double* d_params, double* d_mu, double* d_cov, int* d_info,
                             void* d_work, size_t work_bytes, void* stream);
 
+/* Emulator.__call__ with several parameter rows (emulator.py:382-389): the JOINT conditional of the
+ * B*m weights, component-major (index i*B + b): d_mu[B*m], d_cov[(B*m)^2]. */
+int sf_emulator_joint_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const double* d_params,
+                            double* d_mu, double* d_cov, int* d_info, void* d_work,
+                            size_t work_bytes, void* stream);
+
 /* Transform chain of SpectrumModel.__call__ (spectrum_model.py:287-332): rotational_broaden,
  * doppler_shift, resample, chebyshev_correct, eigenspectrum reconstruction and (re)scaling.
  * Outputs: d_flux[B*n] scaled model flux, d_X[B*m*n] scaled eig*std rows, d_resid[B*n] =

@@ -387,3 +387,26 @@ class DeviceOrder:
             )
             _lib.check(rc, "sf_emulator_query_batch")
             return mu.cpu().numpy(), cov.cpu().numpy(), info.cpu().numpy()
+
+    def emulator_query_joint(self, grid_params):
+        """grid_params: (B, P).  Joint conditional over the B points, component-major: mu (B*m,), cov (B*m, B*m)."""
+        torch = _torch()
+        gp = np.atleast_2d(np.asarray(grid_params, dtype=np.float64))
+        B = gp.shape[0]
+        md = self.model_desc(0, 0, 1, 0, 0, 0)
+        stride = self.param_stride(md)
+        rows = np.zeros((B, stride))
+        rows[:, 3] = 1.0
+        rows[:, 6 : 6 + self.P] = gp
+        with torch.cuda.device(self.dev):
+            P = to_dev(rows, self.dev)
+            mu = empty((B * self.m,), self.dev)
+            cov = empty((B * self.m, B * self.m), self.dev)
+            info = empty((B,), self.dev, torch.int32)
+            ws = self._work(md, B)
+            rc = self.lib.sf_emulator_joint_batch(
+                self.ctx, C.byref(md), B, ptr(P), ptr(mu), ptr(cov), ptr(info), ptr(ws), ws.numel(),
+                stream_ptr(self.dev),
+            )
+            _lib.check(rc, "sf_emulator_joint_batch")
+            return mu.cpu().numpy(), cov.cpu().numpy(), info.cpu().numpy()

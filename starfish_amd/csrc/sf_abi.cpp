@@ -570,8 +570,14 @@ extern "C" size_t sf_workspace_bytes(const sf_ctx* c, const sf_model_desc* mdl, 
 }
 
 // ----------------------------------------------------------------------------------- stages
+static sf_emu_args emu_args(sf_ctx* c, const sf_model_desc* mdl, const double* d_params, const Work& w,
+                            double* d_mu, double* d_cov, double* d_Lw, int* d_info);
 static int run_emulator(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params, const Work& w,
                         double* d_mu, double* d_cov, double* d_Lw, int* d_info, hipStream_t s) {
+    return sf_launch_emulator(emu_args(c, mdl, d_params, w, d_mu, d_cov, d_Lw, d_info), B, s);
+}
+static sf_emu_args emu_args(sf_ctx* c, const sf_model_desc* mdl, const double* d_params, const Work& w,
+                            double* d_mu, double* d_cov, double* d_Lw, int* d_info) {
     sf_emu_args e;
     e.params = d_params;
     e.pstride = sf_param_stride(c, mdl);
@@ -591,7 +597,7 @@ static int run_emulator(sf_ctx* c, const sf_model_desc* mdl, int B, const double
     e.cov = d_cov;
     e.Lw = d_Lw;
     e.info = d_info;
-    return sf_launch_emulator(e, B, s);
+    return e;
 }
 
 // emulator + transform chain -> unscaled X / flux, scale, then residual / Y
@@ -742,6 +748,24 @@ extern "C" int sf_emulator_query_batch(sf_ctx* c, const sf_model_desc* mdl, int 
     int* info = d_info ? d_info : w.info_e;
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s));
     return run_emulator(c, mdl, B, d_params, w, d_mu ? d_mu : w.mu, d_cov, w.Lw, info, s);
+}
+
+extern "C" int sf_emulator_joint_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params,
+                                       double* d_mu, double* d_cov, int* d_info, void* d_work,
+                                       size_t work_bytes, void* stream) {
+    int rc = check_work(c, mdl, B, d_work, work_bytes, false);
+    if (rc) return rc;
+    if (!d_mu || !d_cov) {
+        sf_set_error("sf_emulator_joint_batch: d_mu and d_cov are required");
+        return SF_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    Work w = carve(c, mdl, B, d_work, work_bytes, false);
+    int* info = d_info ? d_info : w.info_e;
+    SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s));
+    rc = run_emulator(c, mdl, B, d_params, w, w.mu, nullptr, nullptr, info, s);
+    if (rc) return rc;
+    return sf_launch_emu_joint(emu_args(c, mdl, d_params, w, w.mu, nullptr, nullptr, info), B, w.mu, d_mu, d_cov, s);
 }
 
 extern "C" int sf_transform_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params,

@@ -101,5 +101,6 @@ struct sf_emu_args {
     int* info;
 };
 int sf_launch_emulator(const sf_emu_args& a, int B, hipStream_t s);
+int sf_launch_emu_joint(const sf_emu_args& a, int B, const double* mu_pts, double* mu, double* cov, hipStream_t s);
 int sf_launch_finish(int B, const double* logdet, const double* sqmah, const int* info, const int* info2,
                      double* lnl, int* info_out, hipStream_t s);

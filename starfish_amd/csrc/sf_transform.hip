@@ -738,6 +738,47 @@ __global__ __launch_bounds__(256) void k_emulator(sf_emu_args a) {
     }
 }
 
+// Joint GP conditional over B query points (Emulator.__call__ with several parameter rows,
+// emulator.py:382-389): with z_b = Linv v12_b left in zscratch by k_emulator,
+//   cov[(i,a),(j,b)] = delta_ij var_i exp(-1/2 |(p_a - p_b)/l_i|^2) - z_a[:, i] . z_b[:, j],
+// indices component-major (i*B + a) as produced by the reference's block-diagonal batch_kernel.
+__global__ __launch_bounds__(256) void k_emu_joint(sf_emu_args a, int B, const double* __restrict__ mu_pts,
+                                                   double* __restrict__ mu, double* __restrict__ cov) {
+    const int n = a.m * B, mM = a.m * a.M;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) {
+        const int i = (int)(e / B), pa = (int)(e - (int64_t)i * B);
+        mu[e] = mu_pts[pa * a.m + i];
+    }
+    if (e >= (int64_t)n * n) return;
+    const int I = (int)(e / n), J = (int)(e - (int64_t)I * n);
+    const int i = I / B, pa = I - i * B, j = J / B, pb = J - j * B;
+    const double* za = a.zscratch + (int64_t)pa * mM * a.m + i;
+    const double* zb = a.zscratch + (int64_t)pb * mM * a.m + j;
+    double acc = 0.0;
+    for (int r = 0; r < mM; ++r) acc += za[(int64_t)r * a.m] * zb[(int64_t)r * a.m];
+    double v22 = 0.0;
+    if (i == j) {
+        const double* Pa = a.params + (int64_t)pa * a.pstride + a.off_grid;
+        const double* Pb = a.params + (int64_t)pb * a.pstride + a.off_grid;
+        double d2 = 0.0;
+        for (int d = 0; d < a.P; ++d) {
+            const double l = a.lengthscales[i * a.P + d];
+            const double df = Pa[d] / l - Pb[d] / l;
+            d2 += df * df;
+        }
+        v22 = a.variances[i] * exp(-0.5 * d2);
+    }
+    cov[e] = v22 - acc;
+}
+
+int sf_launch_emu_joint(const sf_emu_args& a, int B, const double* mu_pts, double* mu, double* cov, hipStream_t s) {
+    const int64_t n = (int64_t)a.m * B, total = n * n;
+    hipLaunchKernelGGL(k_emu_joint, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, B, mu_pts, mu, cov);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
 // d_lnl = -(logdet + sqmah)/2, -inf where info != 0   (spectrum_model.py:405)
 __global__ void k_finish(int B, const double* __restrict__ logdet, const double* __restrict__ sqmah,
                          const int* __restrict__ info, const int* __restrict__ info2,

@@ -146,8 +146,8 @@ class Emulator:
 
         A single parameter vector gives ``mu (m,)`` and ``cov (m, m)``.  With
         ``reinterpret_batch=True`` a list of vectors returns per-point means ``(B, m)`` and variances
-        ``(B, m)``.  (The reference's joint covariance across several query points,
-        ``full_cov=True`` with more than one point, is not on the model path and is not provided.)"""
+        ``(B, m)``; without it several vectors give the joint conditional, component-major
+        (``mu (B m,)``, ``cov (B m, B m)``) as the reference's block-diagonal ``batch_kernel`` orders it."""
         params = np.atleast_2d(np.asarray(params, dtype=np.float64))
         if full_cov and reinterpret_batch:
             raise ValueError("Cannot reshape the full_covariance matrix for many parameters.")
@@ -159,9 +159,11 @@ class Emulator:
         if np.any(params < self.min_params) or np.any(params > self.max_params):
             raise ValueError("Querying emulator outside of original parameter range.")
         if params.shape[0] > 1 and not reinterpret_batch:
-            raise NotImplementedError(
-                "joint covariance across several query points is not provided; use reinterpret_batch=True"
-            )
+            # joint conditional over all query points, component-major like the reference's batch_kernel
+            mu, cov, info = self._dev().emulator_query_joint(params)
+            if np.any(info != 0):
+                raise ValueError(D.INFO_MESSAGES.get(int(info[info != 0][0]), "emulator query failed"))
+            return (mu, cov) if full_cov else (mu, np.diag(cov))
         mu, cov, info = self._dev().emulator_query(params)
         if np.any(info != 0):
             raise ValueError(D.INFO_MESSAGES.get(int(info[info != 0][0]), "emulator query failed"))

@@ -253,6 +253,26 @@ class TestEmulator:
             m_i, v_i = emu(p, full_cov=False, reinterpret_batch=True)
             assert np.allclose(mus[i], m_i) and np.allclose(vars_[i], v_i)
 
+    def test_call_multiple_is_the_joint_conditional(self):
+        from oracle import sf_oracle as O
+
+        emu = make_emulator()
+        params = [[6020, 4.21, -0.01], [6104, 4.01, -0.23], [6054, 4.15, -0.16]]
+        n = emu.ncomps * len(params)
+        mu, cov = emu(params)
+        assert mu.shape == (n,) and cov.shape == (n, n)
+        want_mu, want_cov = O.emulator_query(emu.grid_points, params, emu.variances, emu.lengthscales, emu.v11,
+                                             emu.w_hat)
+        np.testing.assert_allclose(mu, want_mu, rtol=1e-9, atol=1e-9 * np.abs(want_mu).max())
+        np.testing.assert_allclose(cov, want_cov, rtol=1e-9, atol=1e-9 * np.abs(want_cov).max())
+        # its diagonal blocks are the single-point answers, and full_cov=False is its diagonal
+        one_mu, one_cov = emu(params[1])
+        B = len(params)
+        np.testing.assert_allclose(mu[1::B], one_mu, rtol=1e-12)
+        np.testing.assert_allclose(cov[1::B, 1::B], one_cov, rtol=1e-9, atol=1e-12 * np.abs(one_cov).max())
+        _, var = emu(params, full_cov=False)
+        np.testing.assert_allclose(var, np.diag(cov))
+
     def test_warns_before_trained(self):
         with pytest.warns(UserWarning):
             make_emulator(trained=False)([6000, 4.2, 0.0])
