@@ -105,6 +105,10 @@ int sf_chebyshev_correct(const double* d_wave, int n, double wave_max, const dou
  * reference calls the third-party `extinction` package); only the default law is provided. */
 int sf_extinct_ccm89(const double* d_wave, int n, const double* d_flux, int rows, double Av, double Rv,
                      double* d_out, void* stream);
+/* same with a choice of law: 0 = ccm89, 1 = odonnell94 (O'Donnell 1994: CCM89 with new optical/NIR
+ * coefficients), 2 = calzetti00 (Calzetti et al. 2000, eq. 4).  All PARITY UNPINNED (literature formulas). */
+int sf_extinct(const double* d_wave, int n, const double* d_flux, int rows, double Av, double Rv, int law,
+               double* d_out, void* stream);
 
 /* scipy.linalg.cho_factor call site Starfish/models/spectrum_model.py:400 (LAPACK dpotrf).
  * In-place batched lower Cholesky of `batch` matrices, matrix b at d_A + b*stride (doubles),

@@ -175,6 +175,31 @@ def ccm89_a_lambda(wave, a_v, r_v=3.1):
     return a_v * (a + b / r_v)
 
 
+def odonnell94_a_lambda(wave, a_v, r_v=3.1):
+    """O'Donnell (1994, ApJ 422, 158): CCM89 with re-derived a(y), b(y) for 1.1 <= x <= 3.3 um^-1.
+    PARITY UNPINNED (see ccm89_a_lambda)."""
+    w = np.asarray(wave, dtype=np.float64)
+    x = 1e4 / w
+    out = ccm89_a_lambda(w, a_v, r_v)
+    op = (x >= 1.1) & (x <= 3.3)
+    y = x[op] - 1.82
+    a = 1 + 0.104 * y - 0.609 * y**2 + 0.701 * y**3 + 1.137 * y**4 - 1.718 * y**5 - 0.827 * y**6 \
+        + 1.647 * y**7 - 0.505 * y**8
+    b = 1.952 * y + 2.908 * y**2 - 3.989 * y**3 - 7.985 * y**4 + 11.102 * y**5 + 5.491 * y**6 \
+        - 10.805 * y**7 + 3.347 * y**8
+    out = np.array(out, dtype=np.float64)
+    out[op] = a_v * (a + b / r_v)
+    return out
+
+
+def calzetti00_a_lambda(wave, a_v, r_v=4.05):
+    """Calzetti et al. (2000, ApJ 533, 682) eq. 4; A_lambda = Av k(lambda) / Rv.  PARITY UNPINNED."""
+    l = np.asarray(wave, dtype=np.float64) * 1e-4
+    k = np.where(l >= 0.63, 2.659 * (-1.857 + 1.040 / l) + r_v,
+                 2.659 * (-2.156 + 1.509 / l - 0.198 / l**2 + 0.011 / l**3) + r_v)
+    return a_v * k / r_v
+
+
 def extinct_ccm89(wave, flux, a_v, r_v=3.1):
     """flux * 10**(-0.4 A_lambda)  (Starfish/transforms.py:205).  PARITY UNPINNED, see above."""
     return flux * 10 ** (-0.4 * ccm89_a_lambda(wave, a_v, r_v))

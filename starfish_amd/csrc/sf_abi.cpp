@@ -1125,7 +1125,15 @@ extern "C" int sf_extinct_ccm89(const double* d_wave, int n, const double* d_flu
         sf_set_error("sf_extinct_ccm89: bad argument");
         return SF_EINVAL;
     }
-    return sf_launch_extinct_rows(d_wave, n, d_flux, rows, Av, Rv, d_out, (hipStream_t)stream);
+    return sf_launch_extinct_rows(d_wave, n, d_flux, rows, Av, Rv, 0, d_out, (hipStream_t)stream);
+}
+extern "C" int sf_extinct(const double* d_wave, int n, const double* d_flux, int rows, double Av, double Rv, int law,
+                          double* d_out, void* stream) {
+    if (!d_wave || !d_flux || !d_out || n < 0 || rows <= 0 || !(Rv > 0.0) || law < 0 || law > 2) {
+        sf_set_error("sf_extinct: bad argument");
+        return SF_EINVAL;
+    }
+    return sf_launch_extinct_rows(d_wave, n, d_flux, rows, Av, Rv, law, d_out, (hipStream_t)stream);
 }
 
 extern "C" size_t sf_potrf_workspace_bytes(int n, int batch) {

@@ -493,12 +493,39 @@ __device__ __forceinline__ double sf_ccm89_mult(double wave_A, double Av, double
     return pow(10.0, -0.4 * (Av * (a + b / Rv)));
 }
 
+// O'Donnell (1994, ApJ 422, 158): CCM89 with re-derived optical/NIR coefficients for 1.1 <= x <= 3.3 um^-1
+// (continuous with the CCM infrared branch at x = 1.1: a = 0.6689, b = -0.6126); other ranges as CCM89.
+// Calzetti et al. (2000, ApJ 533, 682), eq. 4: k(lambda) = 2.659 (-1.857 + 1.040/l) + Rv for
+// 0.63 um <= l <= 2.2 um and 2.659 (-2.156 + 1.509/l - 0.198/l^2 + 0.011/l^3) + Rv for 0.12 um <= l < 0.63 um,
+// A_lambda = Av k / Rv (k(0.55 um) = Rv).  Outside 0.12 - 2.2 um the nearer branch is extrapolated.
+// Both PARITY UNPINNED like ccm89 (literature formulas; the reference's `extinction` package is unavailable).
+__device__ __forceinline__ double sf_extinct_mult(double wave_A, double Av, double Rv, int law) {
+    if (law == 1) {
+        const double x = 1e4 / wave_A;
+        if (x >= 1.1 && x <= 3.3) {
+            const double y = x - 1.82;
+            const double a = 1 + y * (0.104 + y * (-0.609 + y * (0.701 + y * (1.137 + y * (-1.718 + y * (-0.827 + y * (1.647 + y * -0.505)))))));
+            const double b = y * (1.952 + y * (2.908 + y * (-3.989 + y * (-7.985 + y * (11.102 + y * (5.491 + y * (-10.805 + y * 3.347)))))));
+            return pow(10.0, -0.4 * (Av * (a + b / Rv)));
+        }
+        return sf_ccm89_mult(wave_A, Av, Rv);
+    }
+    if (law == 2) {
+        const double l = wave_A * 1e-4;  // micron
+        const double il = 1.0 / l;
+        const double k = (l >= 0.63) ? 2.659 * (-1.857 + 1.040 * il) + Rv
+                                     : 2.659 * (-2.156 + il * (1.509 + il * (-0.198 + il * 0.011))) + Rv;
+        return pow(10.0, -0.4 * (Av * k / Rv));
+    }
+    return sf_ccm89_mult(wave_A, Av, Rv);
+}
+
 __global__ __launch_bounds__(256) void k_extinct_rows(const double* __restrict__ wave, int n,
                                                       const double* __restrict__ flux, int rows, double Av,
-                                                      double Rv, double* __restrict__ out) {
+                                                      double Rv, int law, double* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double mlt = sf_ccm89_mult(wave[i], Av, Rv);
+    const double mlt = sf_extinct_mult(wave[i], Av, Rv, law);
     for (int r = 0; r < rows; ++r) out[(int64_t)r * n + i] = flux[(int64_t)r * n + i] * mlt;
 }
 
@@ -948,9 +975,9 @@ int sf_launch_resid_y(const sf_resid_args& a, int B, hipStream_t s) {
     return SF_OK;
 }
 
-int sf_launch_extinct_rows(const double* wave, int n, const double* flux, int rows, double Av, double Rv,
+int sf_launch_extinct_rows(const double* wave, int n, const double* flux, int rows, double Av, double Rv, int law,
                            double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_extinct_rows, dim3((n + 255) / 256), dim3(256), 0, s, wave, n, flux, rows, Av, Rv, out);
+    hipLaunchKernelGGL(k_extinct_rows, dim3((n + 255) / 256), dim3(256), 0, s, wave, n, flux, rows, Av, Rv, law, out);
     SF_LAUNCH_CHECK();
     return SF_OK;
 }

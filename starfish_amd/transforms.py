@@ -91,13 +91,16 @@ def extinct(wave, flux, Av, Rv=3.1, law="ccm89"):
     PARITY UNPINNED: the reference obtains ``A_lambda`` from the third-party ``extinction`` C extension,
     which is not part of the reference tree and cannot be run here to generate vectors.  The default law
     ``ccm89`` is implemented from the published Cardelli, Clayton & Mathis (1989) formulas and checked
-    against that paper's Table 3; the other laws raise ``NotImplementedError``."""
+    against that paper's Table 3; ``odonnell94`` (O'Donnell 1994) and ``calzetti00`` (Calzetti et al. 2000,
+    eq. 4) likewise from the literature; the spline-based ``fitzpatrick99`` / ``fm07`` raise
+    ``NotImplementedError``."""
     if law not in ["ccm89", "odonnell94", "calzetti00", "fitzpatrick99", "fm07"]:
         raise ValueError("Invalid extinction law given")
     if Rv <= 0:
         raise ValueError("Rv must be positive")
-    if law != "ccm89":
-        raise NotImplementedError(f"extinction law {law!r} is not provided (only the default 'ccm89')")
+    codes = {"ccm89": 0, "odonnell94": 1, "calzetti00": 2}
+    if law not in codes:
+        raise NotImplementedError(f"extinction law {law!r} is not provided (ccm89, odonnell94, calzetti00 are)")
     lib = _lib.require_gpu()
     wave = np.asarray(wave, dtype=np.float64)
     rows, one_d = _rows(flux)
@@ -105,9 +108,9 @@ def extinct(wave, flux, Av, Rv=3.1, law="ccm89"):
     d_wave = D.to_dev(wave, dev)
     d_flux = D.to_dev(rows, dev)
     d_out = D.empty(rows.shape, dev)
-    rc = lib.sf_extinct_ccm89(D.ptr(d_wave), wave.shape[0], D.ptr(d_flux), rows.shape[0], float(Av), float(Rv),
-                              D.ptr(d_out), D.stream_ptr(dev))
-    _lib.check(rc, "sf_extinct_ccm89")
+    rc = lib.sf_extinct(D.ptr(d_wave), wave.shape[0], D.ptr(d_flux), rows.shape[0], float(Av), float(Rv),
+                        codes[law], D.ptr(d_out), D.stream_ptr(dev))
+    _lib.check(rc, "sf_extinct")
     out = d_out.cpu().numpy()
     return out[0] if one_d else out
 

@@ -178,3 +178,10 @@ def test_extinct_ccm89_unpinned_law(gpu):
         T.extinct(w, f, 1.0, Rv=-1.0)
     with pytest.raises(NotImplementedError):
         T.extinct(w, f, 1.0, law="fm07")
+    # the other two closed-form laws (also unpinned): restated formulas, identity at Av = 0, A(5500 A) = Av
+    for law, alam in (("odonnell94", O.odonnell94_a_lambda), ("calzetti00", O.calzetti00_a_lambda)):
+        np.testing.assert_array_equal(T.extinct(w, f, 0.0, law=law), f)
+        np.testing.assert_allclose(T.extinct(w, f, 0.9, Rv=3.4, law=law), f * 10 ** (-0.4 * alam(w, 0.9, 3.4)),
+                                   rtol=1e-13)
+        v = T.extinct(np.array([5494.5, 5500.0]), np.ones(2), 1.0, Rv=3.1, law=law)
+        assert abs(-2.5 * np.log10(v[1]) - 1.0) < 2e-3

@@ -210,13 +210,17 @@ class TestChebyshevCorrection:
 
 @pytest.mark.gpu
 class TestExtinct:
+    laws = ["ccm89", "odonnell94", "calzetti00"]  # the closed-form laws; fitzpatrick99 / fm07 are not provided
+
+    @pytest.mark.parametrize("law", laws)
     @pytest.mark.parametrize("Av,Rv", [(0.4, 2), (0.6, 3.2), (1, 4), (1.2, 5)])
-    def test_extinct(self, mock_data, Av, Rv):
-        out = extinct(*mock_data, Av=Av, Rv=Rv, law="ccm89")
+    def test_extinct(self, mock_data, law, Av, Rv):
+        out = extinct(*mock_data, Av=Av, Rv=Rv, law=law)
         assert not np.allclose(out, mock_data[1]) and np.all(out < mock_data[1])
 
-    def test_no_extinct(self, mock_data):
-        assert np.allclose(extinct(*mock_data, 0, 3.1, "ccm89"), mock_data[1])
+    @pytest.mark.parametrize("law", laws)
+    def test_no_extinct(self, mock_data, law):
+        assert np.allclose(extinct(*mock_data, 0, 3.1, law), mock_data[1])
 
     def test_bad_laws(self, mock_data):
         with pytest.raises(ValueError):
