@@ -221,3 +221,20 @@ def test_model_with_extinction_matches_oracle_unpinned():
     assert close_lnl(out["lnl"][0], g["full_lnl"][0])
     assert close_lnl(out["lnl"][1], O.log_likelihood(oo, p1))
     assert out["lnl"][0] != out["lnl"][1]
+
+
+@pytest.mark.parametrize("N", [70, 200, 300, 520])
+def test_small_and_ragged_sizes_both_solvers(N):
+    """Orders shorter than one panel, exactly one panel, and with a narrower last panel (padding to 64 for the
+    dense factorisation, to 16 for the banded one): both solvers against the oracle."""
+    o = synth.make_order(N=N, m=4, seed=3)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    plist = [synth.vector_to_oracle_params(p) for p in synth.walker_ball(o, B=5, seed=2)]
+    md, rows = pack_rows(do, plist)
+    dense = do.loglike(md, rows)
+    auto = do.loglike(md, rows, solver="auto")
+    assert (dense["info"] == 0).all() and (auto["info"] == 0).all()
+    for b, p in enumerate(plist):
+        want = O.log_likelihood(oo, p)
+        assert close_lnl(dense["lnl"][b], want) and close_lnl(auto["lnl"][b], want)
