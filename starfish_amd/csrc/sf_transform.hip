@@ -744,24 +744,33 @@ __global__ __launch_bounds__(256) void k_emulator(sf_emu_args a) {
     if (a.cov)
         for (int e = tid; e < a.m * a.m; e += 256) a.cov[(int64_t)b * a.m * a.m + e] = covs[e];
     __syncthreads();
-    if (tid == 0 && a.Lw) {
-        // small dense Cholesky of Sigma_w (spectrum_model.py:334 cho_factor(weights_cov))
-        double* L = a.Lw + (int64_t)b * a.m * a.m;
-        int fail = 0;
-        for (int j = 0; j < a.m; ++j) {
-            double d = covs[j * a.m + j];
-            for (int k = 0; k < j; ++k) d -= L[j * a.m + k] * L[j * a.m + k];
-            if (!(d > 0.0)) { fail = 1; d = 1.0; }
-            const double dj = sqrt(d);
-            L[j * a.m + j] = dj;
-            for (int i = j + 1; i < a.m; ++i) {
-                double v = covs[i * a.m + j];
-                for (int k = 0; k < j; ++k) v -= L[i * a.m + k] * L[j * a.m + k];
-                L[i * a.m + j] = v / dj;
+    if (a.Lw) {
+        // small dense Cholesky of Sigma_w (spectrum_model.py:334 cho_factor(weights_cov)): factor in LDS (in
+        // place in `covs`, lower triangle), one thread, then a parallel copy-out with the upper part zeroed
+        __shared__ int fail;
+        if (tid == 0) {
+            fail = 0;
+            const int m = a.m;
+            for (int j = 0; j < m; ++j) {
+                double d = covs[j * m + j];
+                for (int k = 0; k < j; ++k) d -= covs[j * m + k] * covs[j * m + k];
+                if (!(d > 0.0)) { fail = 1; d = 1.0; }
+                const double dj = sqrt(d), rj = 1.0 / dj;
+                covs[j * m + j] = dj;
+                for (int i = j + 1; i < m; ++i) {
+                    double v = covs[i * m + j];
+                    for (int k = 0; k < j; ++k) v -= covs[i * m + k] * covs[j * m + k];
+                    covs[i * m + j] = v * rj;
+                }
             }
-            for (int i = 0; i < j; ++i) L[i * a.m + j] = 0.0;
+            if (fail && a.info) a.info[b] = SF_INFO_BAD_WEIGHT_COV;
         }
-        if (fail && a.info) a.info[b] = SF_INFO_BAD_WEIGHT_COV;
+        __syncthreads();
+        double* L = a.Lw + (int64_t)b * a.m * a.m;
+        for (int e = tid; e < a.m * a.m; e += 256) {
+            const int i = e / a.m, j = e - i * a.m;
+            L[e] = j <= i ? covs[e] : 0.0;
+        }
     }
 }
 
