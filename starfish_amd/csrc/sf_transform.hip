@@ -39,6 +39,48 @@ __device__ void sf_fft_inplace(double2* buf, int L, const double2* __restrict__ 
     }
 }
 
+// Same transform with two radix-2 stages fused per pass (radix-2^2): half the LDS sweeps and barriers.
+// Input bit-reversed (radix-2 order), output natural, exactly the butterflies of sf_fft_inplace.
+__device__ void sf_fft_inplace_r4(double2* buf, int L, const double2* __restrict__ tw, bool inverse, int twmul = 1) {
+    const int tid = threadIdx.x, nth = blockDim.x;
+    int ls = 0, s = 1;
+    int nst = 0;
+    while ((1 << nst) < L) ++nst;
+    if (nst & 1) {  // odd number of stages: one plain radix-2 stage first (half-size 1, twiddle 1)
+        for (int idx = tid; idx < L / 2; idx += nth) {
+            const double2 u = buf[2 * idx], v = buf[2 * idx + 1];
+            buf[2 * idx] = make_double2(u.x + v.x, u.y + v.y);
+            buf[2 * idx + 1] = make_double2(u.x - v.x, u.y - v.y);
+        }
+        __syncthreads();
+        s = 2;
+        ls = 1;
+    }
+    for (; s < L; s <<= 2, ls += 2) {
+        const int stepA = L / (2 * s) * twmul, stepB = L / (4 * s) * twmul;
+        for (int idx = tid; idx < L / 4; idx += nth) {
+            const int j = idx & (s - 1);
+            const int i0 = ((idx >> ls) << (ls + 2)) + j;
+            double2 wA = tw[j * stepA], wB0 = tw[j * stepB], wB1 = tw[(j + s) * stepB];
+            if (inverse) {
+                wA.y = -wA.y;
+                wB0.y = -wB0.y;
+                wB1.y = -wB1.y;
+            }
+            const double2 x0 = buf[i0], x1 = buf[i0 + s], x2 = buf[i0 + 2 * s], x3 = buf[i0 + 3 * s];
+            const double2 t1 = cmul(wA, x1), t3 = cmul(wA, x3);
+            const double2 a0 = make_double2(x0.x + t1.x, x0.y + t1.y), a1 = make_double2(x0.x - t1.x, x0.y - t1.y);
+            const double2 a2 = make_double2(x2.x + t3.x, x2.y + t3.y), a3 = make_double2(x2.x - t3.x, x2.y - t3.y);
+            const double2 u2 = cmul(wB0, a2), u3 = cmul(wB1, a3);
+            buf[i0] = make_double2(a0.x + u2.x, a0.y + u2.y);
+            buf[i0 + 2 * s] = make_double2(a0.x - u2.x, a0.y - u2.y);
+            buf[i0 + s] = make_double2(a1.x + u3.x, a1.y + u3.y);
+            buf[i0 + 3 * s] = make_double2(a1.x - u3.x, a1.y - u3.y);
+        }
+        __syncthreads();
+    }
+}
+
 // Decimation-in-frequency forward FFT: natural-order input, BIT-REVERSED output (so the product
 // with a real symmetric multiplier feeds the DIT inverse above without any permutation pass).
 __device__ void sf_fft_dif_forward(double2* buf, int L, const double2* __restrict__ tw) {
@@ -199,7 +241,7 @@ __global__ __launch_bounds__(256) void k_broaden_half(const double2* __restrict_
         buf[sf_bitrev((unsigned)k, bits)] = make_double2(E.x - O.y, E.y + O.x);
     }
     __syncthreads();
-    sf_fft_inplace(buf, L, tw, true, 2);
+    sf_fft_inplace_r4(buf, L, tw, true, 2);
     const double inv_n = 1.0 / nf;
     double* o = out + (int64_t)b * ob + (int64_t)row * orow;
     for (int m = tid; m < L; m += 256) {
