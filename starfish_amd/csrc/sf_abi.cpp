@@ -623,10 +623,10 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
         a.pstride = pstride;
         a.poff = 0;
         a.scalar_param = 0.0;
-        a.out = w.ybro;
+        a.out = w.ybro;  // [B][rows][nf]: every row contiguous (coalesced stores)
         a.ob = (int64_t)c->nf * c->rows;
-        a.orow = 1;
-        a.oelem = c->rows;
+        a.orow = c->nf;
+        a.oelem = 1;
         a.gscratch = w.fft;
         a.mult = w.mult;
         a.info = w.info_e;

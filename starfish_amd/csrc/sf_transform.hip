@@ -244,10 +244,18 @@ __global__ __launch_bounds__(256) void k_broaden_half(const double2* __restrict_
     sf_fft_inplace_r4(buf, L, tw, true, 2);
     const double inv_n = 1.0 / nf;
     double* o = out + (int64_t)b * ob + (int64_t)row * orow;
-    for (int m = tid; m < L; m += 256) {
-        const double2 z = buf[m];
-        o[(int64_t)(2 * m) * oelem] = z.x * inv_n;
-        o[(int64_t)(2 * m + 1) * oelem] = z.y * inv_n;
+    if (oelem == 1) {  // contiguous row: one 16-byte store per thread
+        double2* o2 = (double2*)o;
+        for (int m = tid; m < L; m += 256) {
+            const double2 z = buf[m];
+            o2[m] = make_double2(z.x * inv_n, z.y * inv_n);
+        }
+    } else {
+        for (int m = tid; m < L; m += 256) {
+            const double2 z = buf[m];
+            o[(int64_t)(2 * m) * oelem] = z.x * inv_n;
+            o[(int64_t)(2 * m + 1) * oelem] = z.y * inv_n;
+        }
     }
 }
 
@@ -379,10 +387,12 @@ __global__ __launch_bounds__(64) void k_spline_solve(double* __restrict__ data, 
 //   C[16 i's][rows] = sum over the 9 input blocks kb of  T[ib][kb] (16 x 16)  x  Y[16 k's][rows]
 // One wave owns one block of 16 outputs and keeps its 9 T blocks in registers (36 A fragments) while it
 // loops over a chunk of walkers, so the 9.4 MB table is read B/chunk times, not B times; the B operand
-// (lane (k, r) <- y[b][k][r], rows contiguous) and the result are addressed straight in HBM/L2: no LDS.
+// (lane (k, r) <- y[b][r][k], every row contiguous as the FFT kernel writes it) and the result are addressed
+// straight in HBM/L2: no LDS.
 // The walker loop is software pipelined: the fragments of walker b+1 are in flight while the matrix
 // core works on walker b.
-// y / c are [B][n][rows]; tblk is [n/16][SF_IBLK][16][16] (zero outside the band / the matrix).
+// y is [B][rows][n], c is [B][n][rows] (what k_eval_rows reads); tblk is [n/16][SF_IBLK][16][16] (zero outside
+// the band / the matrix).
 #define SF_IBLK (2 * (SF_IW / 16) + 1)
 template <int NCB>
 __global__ __launch_bounds__(256) void k_spline_apply(const double* __restrict__ y, double* __restrict__ c,
@@ -396,24 +406,29 @@ __global__ __launch_bounds__(256) void k_spline_apply(const double* __restrict__
     for (int kb = 0; kb < SF_IBLK; ++kb)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-            a[kb][kk] = tblk[(((int64_t)ib * SF_IBLK + kb) * 16 + l15) * 16 + kk * 4 + lq];
-    const int kbase = (ib - SF_IW / 16) * 16 + lq;
+            a[kb][kk] = tblk[(((int64_t)ib * SF_IBLK + kb) * 16 + l15) * 16 + 4 * lq + kk];  // K slice lq of MFMA kk <-> k = 4 lq + kk
+    const int nblk16 = n / 16;
     const int b0 = blockIdx.y * wchunk, b1 = min(B, b0 + wchunk);
     double bA[SF_IBLK][4][NCB], bB[SF_IBLK][4][NCB];
+    // lane (r = l15, lq) takes the four CONTIGUOUS inputs 4 lq .. 4 lq + 3 of row r of a block (the same
+    // permutation of the summation index as in the coefficient fragments): one 32-byte load per block
     auto fetch = [&](int b, double (&dst)[SF_IBLK][4][NCB]) {
         const double* yb = y + (int64_t)b * n * rows;
 #pragma unroll
-        for (int kb = 0; kb < SF_IBLK; ++kb)
+        for (int kb = 0; kb < SF_IBLK; ++kb) {
+            int kblk = ib - SF_IW / 16 + kb;  // blocks outside the matrix carry zero coefficients
+            kblk = kblk < 0 ? 0 : (kblk >= nblk16 ? nblk16 - 1 : kblk);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                int k = kbase + kb * 16 + kk * 4;  // blocks outside the matrix carry zero coefficients
-                k = k < 0 ? 0 : (k >= n ? n - 1 : k);
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    const int r = cb * 16 + l15;
-                    dst[kb][kk][cb] = yb[k * rows + (r < rows ? r : 0)];  // columns >= rows: never stored
-                }
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int r = cb * 16 + l15;
+                const double2* p = (const double2*)(yb + (int64_t)(r < rows ? r : 0) * n + kblk * 16 + 4 * lq);
+                const double2 lo = p[0], hi = p[1];  // rows >= `rows` are never stored
+                dst[kb][0][cb] = lo.x;
+                dst[kb][1][cb] = lo.y;
+                dst[kb][2][cb] = hi.x;
+                dst[kb][3][cb] = hi.y;
             }
+        }
     };
     auto compute = [&](int b, const double (&bv)[SF_IBLK][4][NCB]) {
         sf_d4x acc[NCB];
