@@ -241,11 +241,12 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
     // X = P L_kk^-T in place, on the matrix cores (B operand = rows of F = L_kk^-1)
     auto xsolve = [&](double* P) {
         sf_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        const double* Ap = P + l15 * BLD + lq;
-        const double* Bp = Fb + l15 * BLD + lq;
+        // (K slice lq of MFMA kk stands for k = 4 lq + kk in both operands: contiguous, paired LDS reads)
+        const double* Ap = P + l15 * BLD + 4 * lq;
+        const double* Bp = Fb + l15 * BLD + 4 * lq;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[kk * 4], Bp[kk * 4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[kk], Bp[kk], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) P[(lq + 4 * r) * BLD + l15] = acc[r];
     };
@@ -267,11 +268,11 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
         sf_d4 acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = Cb[(lq + 4 * r) * ldc + l15];
-        const double* Ap = PI + l15 * BLD + lq;
-        const double* Bp = PJ + l15 * BLD + lq;
+        const double* Ap = PI + l15 * BLD + 4 * lq;
+        const double* Bp = PJ + l15 * BLD + 4 * lq;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[kk * 4], Bp[kk * 4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[kk], Bp[kk], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Cb[(lq + 4 * r) * ldc + l15] = acc[r];
     };
