@@ -238,10 +238,8 @@ class DeviceOrder:
             P = params if torch.is_tensor(params) else to_dev(params, self.dev)
             B = int(P.shape[0])
             chunk = min(B, max_chunk or B, self.max_batch(md))
-            lnl = empty((B,), self.dev)
-            logdet = empty((B,), self.dev)
-            sqmah = empty((B,), self.dev)
-            lsc = empty((B,), self.dev)
+            quad = empty((4, B), self.dev)  # one device->host copy for the four double outputs
+            lnl, logdet, sqmah, lsc = quad[0], quad[1], quad[2], quad[3]
             info = empty((B,), self.dev, torch.int32)
             resid = empty((B, self.n), self.dev) if want_resid else None
             s = stream_ptr(self.dev)
@@ -254,13 +252,8 @@ class DeviceOrder:
                     ptr(info[lo:hi]), ptr(ws), ws.numel(), s,
                 )
                 _lib.check(rc, "sf_loglike_batch")
-            out = dict(
-                lnl=lnl.cpu().numpy(),
-                logdet=logdet.cpu().numpy(),
-                sqmah=sqmah.cpu().numpy(),
-                log_scale=lsc.cpu().numpy(),
-                info=info.cpu().numpy(),
-            )
+            host = quad.cpu().numpy()
+            out = dict(lnl=host[0], logdet=host[1], sqmah=host[2], log_scale=host[3], info=info.cpu().numpy())
             if want_resid:
                 out["resid"] = resid.cpu().numpy()
             return out
@@ -292,7 +285,8 @@ class DeviceOrder:
             with torch.cuda.device(self.dev):
                 P = to_dev(rows[idx], self.dev)
                 nb = idx.size
-                lnl, logdet, sqmah, lsc = (empty((nb,), self.dev) for _ in range(4))
+                quad = empty((4, nb), self.dev)  # one device->host copy for the four double outputs
+                lnl, logdet, sqmah, lsc = quad[0], quad[1], quad[2], quad[3]
                 info = empty((nb,), self.dev, torch.int32)
                 resid = empty((nb, self.n), self.dev) if want_resid else None
                 chunk = min(nb, max_chunk or nb)
@@ -302,8 +296,10 @@ class DeviceOrder:
                         md, P[lo:hi], W, lnl[lo:hi], info[lo:hi], logdet[lo:hi], sqmah[lo:hi],
                         resid[lo:hi] if want_resid else None, lsc[lo:hi],
                     )
-                for key, t in (("lnl", lnl), ("logdet", logdet), ("sqmah", sqmah), ("log_scale", lsc), ("info", info)):
-                    out[key][idx] = t.cpu().numpy()
+                host = quad.cpu().numpy()
+                for row, key in enumerate(("lnl", "logdet", "sqmah", "log_scale")):
+                    out[key][idx] = host[row]
+                out["info"][idx] = info.cpu().numpy()
                 if want_resid:
                     out["resid"][idx] = resid.cpu().numpy()
         rest = np.nonzero(~fits | (out["info"] == INFO_BANDWIDTH))[0] if solver == "auto" else np.array([], dtype=int)

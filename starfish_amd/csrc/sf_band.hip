@@ -36,11 +36,13 @@
 // (W rounded up to 16)-row separator, k_band_merge adds the two Schur contributions and a short third
 // sweep finishes the separator: 0.89 ms instead of 1.52.
 #include "sf_common.h"
+#include <type_traits>
 
 #define BB 16
 #define BS (BB * (BB + 1))  // doubles per stored block (row stride 17: conflict-free fragment reads)
 #define BLD (BB + 1)
 #define SFB_PF 4            // prefetch registers per thread
+#define SFB_PT 8            // update pairs per wave (table row; the last entry is the count)
 
 struct sf_band_args {
     const double* band;  // [batch] x sband : band[i*ldb + d] = A[i][i-d], d in [0, halfwidth]
@@ -140,11 +142,17 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
     constexpr int NR = NRB * BB, LDG = NR + 1;
     double* Wb = lds;                                  // nbr(nbr+1)/2 band blocks
     double* RH = Wb + (nbr * (nbr + 1) / 2) * BS;      // [NRB][nbr] right-hand-side blocks (column ring)
-    double* Fb = RH + NRB * nbr * BS;                  // inverse of the current diagonal factor, L_kk^-1
-    double* G = Fb + BS;                               // [NR][LDG]   Gram accumulator
+    double* Fb2 = RH + NRB * nbr * BS;                 // [2] inverse of the diagonal factor, L_kk^-1 (by parity of k)
+    double* G = Fb2 + 2 * BS;                          // [NR][LDG]   Gram accumulator
     double* pv = G + NR * LDG;                         // [2][16] pivots (for the log-determinant)
     double* red = pv + 2 * BB;                         // [16] reduction scratch
-    volatile int* sync = (volatile int*)(red + BB);   // [0] diagonal factor ready (kb+1), [1] waves that placed block 0
+    typedef __attribute__((address_space(3))) int lds_int_t;  // ds_read / ds_add, not flat accesses
+    // progress flags of the software pipeline (all monotonic):
+    //   [0] F_k published (k+1)          [1] waves that placed block 0 of the newest row (4 per step)
+    //   [2] X_{k+1,k} published (k+1)    [3] wave 0 done with column k (k+1)
+    //   [4] workers done with column k (k+1)   [5] worker barrier arrivals   [7] a spin timed out
+    volatile lds_int_t* sync = (volatile lds_int_t*)(red + BB);
+    volatile lds_int_t* ptab = sync + 16;              // [16 waves][SFB_PT] (I << 8 | J) update pairs, [..][SFB_PT-1] = count
 
     const int n = a.n, W = a.halfwidth;
     const int nblk = (n + BB - 1) / BB;
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
             }
         }
     for (int e = tid; e < NR * LDG; e += nthreads) G[e] = 0.0;
-    if (tid < 2) sync[tid] = 0;
+    if (tid < 16) sync[tid] = 0;
 
     const int l15 = lane & 15, lq = lane >> 4;
     // Wave 0: Cholesky of the 16 x 16 diagonal block AND the inverse of its factor, both kept in the
@@ -187,7 +195,6 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
             acc[r] = D[max(row, l15) * BLD + min(row, l15)];  // only the lower triangle is maintained
             f[r] = row == l15 ? 1.0 : 0.0;
         }
-        __builtin_amdgcn_s_setprio(3);  // the other waves of this SIMD are doing bulk MFMA work
         double p = sfb_readlane(acc[0], 0);
         double pkeep = 1.0;  // lane j keeps pivot j: one LDS store and one sign test after the loop
 #pragma unroll
@@ -206,185 +213,287 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
                 const double vn = sfb_readlane(v, qj * 16 + j + 1);
                 p = __builtin_fma(-vn, vn, an);
             }
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, acc, 0, 0, 0);
-            f = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, g, f, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 1);  // blgp = neg:[1,0,0]: -A B + C
+            f = __builtin_amdgcn_mfma_f64_16x16x4f64(v, g, f, 0, 0, 1);
         }
         if (lane < BB) pv[(kb & 1) * BB + lane] = pkeep;
         const unsigned long long neg = __ballot(lane < BB && !(pkeep > 0.0));
         if (neg && !bad) bad = kb * BB + __ffsll((long long)neg);
-        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Fb[(lq + 4 * r) * BLD + l15] = f[r];
+        for (int r = 0; r < 4; ++r) Fb2[(kb & 1) * BS + (lq + 4 * r) * BLD + l15] = f[r];
     };
-    __syncthreads();
-    if (wave == 0) potrf16(0, 0);
 
-    // prefetch roles: fixed (row, column) inside a block per thread, only the block index varies
+    // Prefetch roles, fixed per thread: waves >= 4 load the band (groups of 256 threads = one 16 x 16
+    // block each, element (pr, pc) of it), waves 1..3 the right-hand-side columns.  Per slot: a running
+    // source pointer (one block row further every step) and the LDS offset of the element inside its
+    // destination block; whether a slot loads at all is a per-thread constant, whether its row is still
+    // inside the matrix is one comparison per step (top-down sweeps only).
     const int ngroups = (nwaves - 4) >> 2;             // 256-thread groups of band loaders (1..3)
-    const int lt = tid - 256;                          // band loader index (waves >= 4)
-    const int pr = (lt >> 4) & 15, pc = lt & 15, pg = lt >> 8;
-    const int rt = tid - 64;                           // rhs loader index (waves 1..3)
-    double pf[SFB_PF];                                 // prefetched values (band or rhs)
-    int pfcode = 0;                                    // 2 bits per slot: 0 -> 0.0, 1 -> pf, 2 -> 1.0
+    const int pg = wave >= 4 ? (wave - 4) >> 2 : 0;    // this wave's group (uniform)
+    const bool band_loader = wave >= 4;
+    typedef const double __attribute__((address_space(1))) * gptr_t;  // keeps the prefetch on global_load
+    gptr_t pptr[SFB_PF];
+    int poff[SFB_PF];
+    int pmask = 0;                                     // bit q: slot q loads; bit 4+q: identity padding when out of range
+    int prow;                                          // padded-matrix row of this thread's elements (next block row)
+    const int pstep = (rev >= 0 ? -BB : BB) * (band_loader ? a.ldb : 1);  // doubles per step
+    {
+        const int lt = tid - 256, pr = (lt >> 4) & 15, pc = lt & 15;
+        const int rt = tid - 64;
+        prow = nbr * BB + (band_loader ? pr : (rt & 15));
+#pragma unroll
+        for (int q = 0; q < SFB_PF; ++q) {
+            if (band_loader) {
+                const int blk = pg + q * ngroups;
+                const int d = (nbr - 1 - blk) * BB + pr - pc;
+                const int io = rev >= 0 ? rev - prow + d : prow;  // larger original index of the pair
+                const bool okd = blk < nbr && d >= 0 && d <= W;
+                pmask |= (okd ? 1 : 0) << q;
+                pmask |= ((blk < nbr && d == 0) ? 16 : 0) << q;
+                pptr[q] = (gptr_t)(band + (int64_t)io * a.ldb + (okd ? d : 0));
+                poff[q] = pr * BLD + pc;
+            } else {
+                const int e = rt + q * 192, r = e >> 4;
+                const int io = rev >= 0 ? rev - prow : prow;
+                const bool okr = wave >= 1 && e < NR * BB && r < a.nrhs;
+                pmask |= (okr ? 1 : 0) << q;
+                const int rr = rhs0 ? (r > 0 ? r - 1 : 0) : r;
+                pptr[q] = (gptr_t)(((rhs0 && r == 0) ? rhs0 : rhs + (int64_t)rr * a.ldr) + io);
+                poff[q] = (wave >= 1 && e < NR * BB) ? (e >> 8) * nbr * BS + ((e >> 4) & 15) * BLD + (e & 15) : -1;
+            }
+        }
+    }
+    double pf[SFB_PF];                                 // prefetched values (band or rhs), final when they land
     double ld_acc = 0.0;                               // wave 1, lanes 0..15: partial sums of log(pivot)
     __syncthreads();
 
     const int nb1 = nbr - 1, RB = nb1 + NRB;
     auto spin_until = [&](int which, int target) {
-        while (sync[which] < target) __builtin_amdgcn_s_sleep(1);
+        int guard = 0;
+        while (sync[which] < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++guard > (1 << 22)) {  // cannot happen; keeps a logic error from hanging the GPU
+                sync[7] = 1;
+                break;
+            }
+        }
         asm volatile("" ::: "memory");
     };
-    // helpers on column block kb (ring slot ks)
-    auto pblock_at = [&](int ks_, int I) -> double* {  // row block I below the diagonal block
-        return I < nb1 ? Wb + sfb_pair(wrap(ks_ + 1 + I), ks_) * BS : RH + ((I - nb1) * nbr + ks_) * BS;
+    auto publish = [&](int which, int value) {  // after this wave's LDS writes have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) sync[which] = value;
     };
-    // X = P L_kk^-T in place, on the matrix cores (B operand = rows of F = L_kk^-1)
-    auto xsolve = [&](double* P) {
+    // ---- block addressing.  Every 16 x 16 block lives at lds + index * BS: window blocks by ring-slot pair,
+    //      then the right-hand-side ring (index NBW + rb * nbr + slot).  Which blocks an operation touches
+    //      depends on the ring phase ks = k % nbr only, so each wave tabulates its operations ONCE, lane ks
+    //      of a VGPR holding the packed block indices for that phase; per step one v_readlane replaces
+    //      the scalar index arithmetic (pair(), wrap(), the band/rhs/Gram case split), which otherwise
+    //      costs more issue time than the MFMAs it feeds.
+    const int NBW = nbr * (nbr + 1) / 2;
+    auto idxP = [&](int ks_, int I) {  // row block I below the diagonal block of column ks_
+        return I < nb1 ? sfb_pair(wrap(ks_ + 1 + I), ks_) : NBW + (I - nb1) * nbr + ks_;
+    };
+    auto pack_update = [&](int ks_, int I, int J) {  // A | B << 8 | C << 16 | gram << 24
+        int c, gram = 0;
+        if (J >= nb1) {
+            c = (I - nb1) * 4 + (J - nb1);
+            gram = 1;
+        } else if (I < nb1) {
+            c = sfb_pair(wrap(ks_ + 1 + I), wrap(ks_ + 1 + J));
+        } else {
+            c = NBW + (I - nb1) * nbr + wrap(ks_ + 1 + J);
+        }
+        return idxP(ks_, I) | (idxP(ks_, J) << 8) | (c << 16) | (gram << 24);
+    };
+    const int tl = lane < nbr ? lane : 0;  // ring phase this lane tabulates
+    const int oAB = l15 * BLD + 4 * lq;   // operand fragment (K slice lq = columns 4 lq .. 4 lq + 3 of row l15)
+    // X = P F^T in place (B operand = rows of F = L_kk^-1; K slice lq of MFMA kk stands for k = 4 lq + kk
+    // in both operands: contiguous, paired LDS reads)
+    auto xsolve = [&](int pidx, const double* Fb) {
+        double* P = lds + pidx * BS;
         sf_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        // (K slice lq of MFMA kk stands for k = 4 lq + kk in both operands: contiguous, paired LDS reads)
-        const double* Ap = P + l15 * BLD + 4 * lq;
-        const double* Bp = Fb + l15 * BLD + 4 * lq;
+        const double* Ap = P + oAB;
+        const double* Bp = Fb + oAB;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[kk], Bp[kk], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) P[(lq + 4 * r) * BLD + l15] = acc[r];
     };
-    // Block (I, J), I >= J, of [band rows below ; rhs rows] x [same]:  C -= P_I P_J^T.  The Gram blocks
-    // accumulate with the same sign (G = -Z Z^T, negated on output).
-    auto update = [&](int ks_, int I, int J) {
-        const double* PI = pblock_at(ks_, I);
-        const double* PJ = pblock_at(ks_, J);
+    // Trailing update  C -= P_I P_J^T  of block (I, J), I >= J, of [band rows below ; rhs rows] x [same]
+    // (Gram blocks accumulate with the same sign: G = -Z Z^T, negated on output), split into its operand
+    // reads and its MFMAs + write-back so that the next block's operands can be read under the MFMAs.
+    auto load_ops = [&](int w, sf_d4& c, sf_d4& av, sf_d4& bv, int& ldc) -> double* {
+        const double* Ap = lds + (w & 255) * BS + oAB;
+        const double* Bp = lds + ((w >> 8) & 255) * BS + oAB;
+        const int ci = (w >> 16) & 255;
         double* Cb;
-        int ldc = BLD;
-        if (J >= nb1) {
-            Cb = G + ((I - nb1) * BB) * LDG + (J - nb1) * BB;
+        if (w >> 24) {
             ldc = LDG;
-        } else if (I < nb1) {
-            Cb = Wb + sfb_pair(wrap(ks_ + 1 + I), wrap(ks_ + 1 + J)) * BS;
+            Cb = G + ((ci >> 2) * BB) * LDG + (ci & 3) * BB + lq * LDG + l15;
         } else {
-            Cb = RH + ((I - nb1) * nbr + wrap(ks_ + 1 + J)) * BS;
+            ldc = BLD;
+            Cb = lds + ci * BS + lq * BLD + l15;
         }
-        sf_d4 acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = Cb[(lq + 4 * r) * ldc + l15];
-        const double* Ap = PI + l15 * BLD + 4 * lq;
-        const double* Bp = PJ + l15 * BLD + 4 * lq;
+        for (int r = 0; r < 4; ++r) c[r] = Cb[4 * r * ldc];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[kk], Bp[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) {
+            av[kk] = Ap[kk];
+            bv[kk] = Bp[kk];
+        }
+        return Cb;
+    };
+    auto mma_store = [&](double* Cb, int ldc, sf_d4 c, const sf_d4& av, const sf_d4& bv) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cb[(lq + 4 * r) * ldc + l15] = acc[r];
+        for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 1);  // neg:[1,0,0]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cb[4 * r * ldc] = c[r];
     };
 
-    // step 0: every row block of the initial window is solved against L_00
-    for (int I = wave; I < RB; I += nwaves) xsolve(pblock_at(0, I));
-    sfb_barrier();
+    // ---- division of labour.  Wave 0 runs the sequential chain by itself and never meets a barrier:
+    //          potrf(k) -> F_k | X_{k+1,k} = A_{k+1,k} F_k^T | D_{k+1} -= X X^T | potrf(k+1) ...
+    //      The other waves ("workers") trail by one column: they solve the rest of block column k against
+    //      F_k, apply column k to the window (every block pair except (0,0)), fetch the next 16 rows from
+    //      HBM and place them into the slots column k retires.  Flags in LDS order the two.
+    const int nworkers = nwaves - 1;
+    const int nprim = nwaves - (nwaves >> 2);          // workers that do not share wave 0's SIMD
+    // position of this wave among the workers, those on wave 0's SIMD last
+    const int wpos = wave == 0 ? -1 : (wave & 3) ? wave - 1 - (wave >> 2) : nprim + (wave >> 2) - 1;
+    if (tid >= 1 && tid < nwaves) {
+        // pair list of wave `tid`: the workers off wave 0's SIMD own two shares each, the others one
+        const int w = tid, wp = (w & 3) ? w - 1 - (w >> 2) : nprim + (w >> 2) - 1;
+        const int nshares = 2 * nprim + (nworkers - nprim);
+        const int npairs = RB * (RB + 1) / 2;
+        int cnt = 0;
+        for (int share = 0; share < nshares; ++share) {
+            const int owner = share < 2 * nprim ? share % nprim : share - nprim;
+            if (owner != wp) continue;
+            for (int t = 1 + share; t < npairs; t += nshares) {
+                int I = 0;
+                while ((I + 1) * (I + 2) / 2 <= t) ++I;
+                if (cnt < SFB_PT - 1) ptab[w * SFB_PT + cnt] = (I << 8) | (t - I * (I + 1) / 2);
+                ++cnt;
+            }
+        }
+        ptab[w * SFB_PT + SFB_PT - 1] = cnt < SFB_PT ? cnt : SFB_PT - 1;
+        if (cnt >= SFB_PT) sync[7] = 1;  // cannot happen for the window sizes the launcher admits
+    }
+    __syncthreads();
 
-    int ks = 0;  // kb % nbr
-    for (int kb = 0; kb < kend; ++kb, ks = wrap(ks + 1)) {
-        // ---- X: the prefetched block row kb-1+nbr lands in the slots retired by column kb-1; the wave
-        //      that owns the update of that row solves its block of column kb as soon as the four waves
-        //      holding it have stored it (LDS counter, no workgroup barrier); every wave then applies
-        //      block column kb+1 of the trailing update (J = 0), which the next diagonal block and the
-        //      next solve depend on.
-        if (kb > 0) {
-            const int rs = ks == 0 ? nbr - 1 : ks - 1;
-            if (wave >= 4) {
+    if (wave == 0) {
+        // lane ks: P0 = block (k+1, k) | D_{k+1} << 8
+        const int tab0 = idxP(tl, 0) | (sfb_pair(wrap(tl + 1), wrap(tl + 1)) << 8);
+        __builtin_amdgcn_s_setprio(3);  // the other waves of this SIMD do bulk MFMA work
+        int ks = 0;
+        for (int kb = 0; kb < kend; ++kb, ks = wrap(ks + 1)) {
+            potrf16(kb, ks);
+            publish(0, kb + 1);
+            const int w0 = __builtin_amdgcn_readlane(tab0, ks);
+            const int p0 = w0 & 255;
+            spin_until(4, kb);                       // column kb-1 fully applied by the workers
+            xsolve(p0, Fb2 + (kb & 1) * BS);
+            publish(2, kb + 1);
+            {                                        // the next diagonal block
+                sf_d4 c, av, bv;
+                int ldc;
+                double* Cb = load_ops(p0 | (p0 << 8) | ((w0 >> 8) << 16), c, av, bv, ldc);
+                mma_store(Cb, ldc, c, av, bv);
+            }
+            publish(3, kb + 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        const int mycnt = __builtin_amdgcn_readfirstlane(ptab[wave * SFB_PT + SFB_PT - 1]);
+        // operation tables (lane = ring phase)
+        int tabu[SFB_PT - 1];
+#pragma unroll
+        for (int p = 0; p < SFB_PT - 1; ++p) {
+            const int e = __builtin_amdgcn_readfirstlane(ptab[wave * SFB_PT + (p < mycnt ? p : 0)]);
+            tabu[p] = p < mycnt ? pack_update(tl, e >> 8, e & 255) : 0;
+        }
+        const int xI0 = 1 + wpos, xI1 = 1 + wpos + nworkers;  // row blocks this wave solves (at most two)
+        const int tabx = (xI0 < RB ? idxP(tl, xI0) : 0) | ((xI1 < RB ? idxP(tl, xI1) : 0) << 8);
+        int tabp = 0;  // band loaders: destination block of prefetch slot q when column slot `lane` retires
+#pragma unroll
+        for (int q = 0; q < SFB_PF; ++q) {
+            const int blk = pg + q * ngroups;
+            tabp |= (blk < nbr ? sfb_pair(tl, wrap(tl + 1 + blk)) : 0) << (8 * q);
+        }
+        int arrivals = 0;
+        auto worker_barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            arrivals += nworkers;
+            if (lane == 0) __hip_atomic_fetch_add((lds_int_t*)&sync[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            spin_until(5, arrivals);
+        };
+        int ks = 0;
+        for (int kb = 0; kb < kend; ++kb, ks = wrap(ks + 1)) {
+            // ---- solve block column kb (row block 0 is wave 0's)
+            const int wx = __builtin_amdgcn_readlane(tabx, ks);
+            spin_until(0, kb + 1);
+            if (xI0 < RB) {
+                if (xI0 == nb1 - 1 && kb > 0) spin_until(1, 4 * kb);  // the newest row: placed by four waves
+                xsolve(wx & 255, Fb2 + (kb & 1) * BS);
+            }
+            if (xI1 < RB) {
+                if (xI1 == nb1 - 1 && kb > 0) spin_until(1, 4 * kb);
+                xsolve((wx >> 8) & 255, Fb2 + (kb & 1) * BS);
+            }
+            if (wave == 1 && lane < BB) ld_acc += log(pv[(kb & 1) * BB + lane]);
+            worker_barrier();
+            // ---- HBM prefetch of block row kb + nbr (lands after the updates)
+            if (kb + 1 < kend) {
+                // straight-line code: all loads are issued back to back, nothing here reads their results.
+                // Rows beyond the matrix (padding up to a multiple of 16) become identity rows; a bottom-up
+                // sweep never leaves the matrix (its order is a multiple of 16).
+                const bool inr = rev >= 0 || prow < n;
+                const int live = inr ? pmask : 0;
+#pragma unroll
+                for (int q = 0; q < SFB_PF; ++q) {
+                    pf[q] = (!inr && ((pmask >> (4 + q)) & 1)) ? 1.0 : 0.0;
+                    if ((live >> q) & 1) pf[q] = *pptr[q];
+                    pptr[q] += pstep;
+                }
+                prow += BB;
+            }
+            // ---- apply column kb to the window (operands of the next block are read while the matrix
+            //      core works on the current one)
+            spin_until(2, kb + 1);
+            {
+                sf_d4 cA, aA, bA, cB, aB, bB;
+                double *pA = nullptr, *pB = nullptr;
+                int ldA = BLD, ldB = BLD;
+                if (mycnt > 0) pA = load_ops(__builtin_amdgcn_readlane(tabu[0], ks), cA, aA, bA, ldA);
+#pragma unroll
+                for (int p = 0; p < SFB_PT - 1; p += 2) {
+                    if (p + 1 < SFB_PT - 1 && p + 1 < mycnt) pB = load_ops(__builtin_amdgcn_readlane(tabu[p + 1 < SFB_PT - 1 ? p + 1 : 0], ks), cB, aB, bB, ldB);
+                    if (p < mycnt) mma_store(pA, ldA, cA, aA, bA);
+                    if (p + 2 < SFB_PT - 1 && p + 2 < mycnt) pA = load_ops(__builtin_amdgcn_readlane(tabu[p + 2 < SFB_PT - 1 ? p + 2 : 0], ks), cA, aA, bA, ldA);
+                    if (p + 1 < SFB_PT - 1 && p + 1 < mycnt) mma_store(pB, ldB, cB, aB, bB);
+                }
+            }
+            worker_barrier();
+            if (wave == 1) publish(4, kb + 1);
+            // ---- the prefetched rows land in the slots of column kb
+            if (kb + 1 < kend) {
+                spin_until(3, kb + 1);
+                const int wp = __builtin_amdgcn_readlane(tabp, ks);
 #pragma unroll
                 for (int q = 0; q < SFB_PF; ++q) {
                     const int blk = pg + q * ngroups;
-                    const int code = (pfcode >> (2 * q)) & 3;
-                    if (blk < nbr)
-                        Wb[sfb_pair(rs, wrap(rs + 1 + blk)) * BS + pr * BLD + pc] = code == 1 ? pf[q] : code == 2 ? 1.0 : 0.0;
+                    if (band_loader && blk >= nbr) continue;
+                    const int uni = band_loader ? ((wp >> (8 * q)) & 255) * BS : (NBW + ks) * BS;
+                    if (poff[q] >= 0) lds[uni + poff[q]] = pf[q];
                 }
-                if (wave < 8) {  // group 0 holds block 0 = (new row, column kb) in its first register
+                if (wave >= 4 && wave < 8) {  // group 0 holds block 0 = (new row, column kb+1) in its first register
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_fetch_add((int*)&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            } else if (wave >= 1) {
-#pragma unroll
-                for (int q = 0; q < SFB_PF; ++q) {
-                    const int e = rt + q * 192;
-                    if (e < NR * BB)
-                        RH[((e >> 8) * nbr + rs) * BS + ((e >> 4) & 15) * BLD + (e & 15)] = ((pfcode >> (2 * q)) & 1) ? pf[q] : 0.0;
+                    if (lane == 0) __hip_atomic_fetch_add((lds_int_t*)&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
-        for (int I = wave; I < RB; I += nwaves) {
-            if (I == nb1 - 1 && kb > 0) {
-                spin_until(1, 4 * kb);
-                xsolve(pblock_at(ks, I));
-            }
-            update(ks, I, 0);
-        }
-        sfb_barrier();
-
-        // ---- S: wave 0 -> next diagonal block and its inverse; the others -> HBM prefetch, rest of the
-        //      trailing update, log(pivot).  Whoever is done waits for the factor (LDS flag) and solves
-        //      its share of the row blocks of column kb+1 -- they were finished by phase X.
-        if (wave == 0) {
-            if (kb + 1 < kend) {
-                potrf16(kb + 1, wrap(ks + 1));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) sync[0] = kb + 1;
-            }
-        } else {
-            if (kb + 1 < kend) {
-                const int gb = kb + nbr;
-                // straight-line code: all loads are issued back to back and nothing here reads their
-                // results (pfcode says in phase X whether a slot takes the loaded value, 1.0 or 0.0)
-                pfcode = 0;
-                if (wave >= 4) {
-                    const int i = gb * BB + pr;
-#pragma unroll
-                    for (int q = 0; q < SFB_PF; ++q) {
-                        const int blk = pg + q * ngroups;
-                        const int d = (nbr - 1 - blk) * BB + pr - pc;
-                        const int io = rev >= 0 ? rev - i + d : i;  // larger original index of the pair
-                        const bool ok = blk < nbr && d >= 0 && d <= W && io < n;
-                        const bool one = blk < nbr && d == 0 && io >= n;
-                        pfcode |= (ok ? 1 : one ? 2 : 0) << (2 * q);
-                        pf[q] = *(ok ? band + (int64_t)io * a.ldb + d : band);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < SFB_PF; ++q) {
-                        const int e = rt + q * 192, r = e >> 4;
-                        const int i = gb * BB + (e & 15);
-                        const int io = rev >= 0 ? rev - i : i;
-                        const bool ok = e < NR * BB && r < a.nrhs && io < n && io >= 0;
-                        const double* src = (rhs0 && r == 0) ? rhs0 + io : rhs + (int64_t)(rhs0 ? r - 1 : r) * a.ldr + io;
-                        pfcode |= (ok ? 1 : 0) << (2 * q);
-                        pf[q] = *(ok ? src : band);
-                    }
-                }
-            }
-            // pairs (I, J), 1 <= J <= I < RB, in triangular order; wave w takes every (nwaves-1)-th
-            // (the waves that share wave 0's SIMD -- every fourth one -- stay out of the way of the
-            // factorisation, which is the critical path of this phase)
-            const int nworkers = nwaves - (nwaves >> 2);
-            int Ip = 0, Jp = (wave & 3) ? wave - 1 - (wave >> 2) : 0x7fff;
-            for (;;) {
-                while (Jp > Ip) {
-                    Jp -= Ip + 1;
-                    ++Ip;
-                    if (Ip > RB - 2) break;
-                }
-                if (Ip > RB - 2) break;
-                update(ks, Ip + 1, Jp + 1);
-                Jp += nworkers;
-            }
-            if (wave == 1 && lane < BB) ld_acc += log(pv[(kb & 1) * BB + lane]);
-        }
-        if (kb + 1 < kend) {
-            spin_until(0, kb + 1);
-            const int ksn = wrap(ks + 1);
-            for (int I = wave; I < RB; I += nwaves)
-                if (I != nb1 - 1) xsolve(pblock_at(ksn, I));  // the newest row arrives in phase X
-        }
-        sfb_barrier();
     }
+    __syncthreads();
 
     // ---- outputs
     if (wave == 1 && lane < BB) red[lane] = ld_acc;
@@ -392,7 +501,8 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
     double ldsum = 0.0;
     if (tid == 0) {
         for (int i = 0; i < BB; ++i) ldsum += red[i];
-        if (bad && a.info && a.info[b] == 0) {
+        if (sync[7] && a.info) a.info[b] = -5;  // internal: pipeline flag wait timed out
+        else if (bad && a.info && a.info[b] == 0) {
             // bottom-up half: report the column in the original numbering
             a.info[b] = half ? nblk * BB - bad + 1 : bad + a.info_off;
         }
@@ -517,7 +627,8 @@ __global__ __launch_bounds__(64) void k_woodbury(const double* __restrict__ gram
 // ------------------------------------------------------------------------------------ launchers
 static size_t band_lds_bytes(int nbr, int nrb) {
     const size_t nr = (size_t)nrb * BB;
-    return sizeof(double) * ((size_t)nbr * (nbr + 1) / 2 * BS + (size_t)nrb * nbr * BS + BS + nr * (nr + 1) + 4 * BB);
+    return sizeof(double) * ((size_t)nbr * (nbr + 1) / 2 * BS + (size_t)nrb * nbr * BS + 2 * BS + nr * (nr + 1) + 4 * BB +
+                             16 * SFB_PT / 2);  // window, rhs ring, two F, Gram, pivots/flags, pair table
 }
 
 static int band_nbr(int halfwidth) {  // window rows >= W + 16, and at least three blocks (see S2)
