@@ -264,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
         }
     }
     double pf[SFB_PF];                                 // prefetched values (band or rhs), final when they land
-    double ld_acc = 0.0;                               // wave 1, lanes 0..15: partial sums of log(pivot)
+    double ld_acc = 0.0;                               // wave `logwave`, lanes 0..15: partial sums of log(pivot)
     __syncthreads();
 
     const int nb1 = nbr - 1, RB = nb1 + NRB;
@@ -357,24 +357,21 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
     //      F_k, apply column k to the window (every block pair except (0,0)), fetch the next 16 rows from
     //      HBM and place them into the slots column k retires.  Flags in LDS order the two.
     const int nworkers = nwaves - 1;
+    const int logwave = nwaves - 4;                    // accumulates log(pivot): no solves, the smallest share of updates
     const int nprim = nwaves - (nwaves >> 2);          // workers that do not share wave 0's SIMD
     // position of this wave among the workers, those on wave 0's SIMD last
     const int wpos = wave == 0 ? -1 : (wave & 3) ? wave - 1 - (wave >> 2) : nprim + (wave >> 2) - 1;
     if (tid >= 1 && tid < nwaves) {
-        // pair list of wave `tid`: the workers off wave 0's SIMD own two shares each, the others one
+        // pair list of wave `tid`: round robin over the workers, those on wave 0's SIMD last (the
+        // remainder goes to the others)
         const int w = tid, wp = (w & 3) ? w - 1 - (w >> 2) : nprim + (w >> 2) - 1;
-        const int nshares = 2 * nprim + (nworkers - nprim);
         const int npairs = RB * (RB + 1) / 2;
         int cnt = 0;
-        for (int share = 0; share < nshares; ++share) {
-            const int owner = share < 2 * nprim ? share % nprim : share - nprim;
-            if (owner != wp) continue;
-            for (int t = 1 + share; t < npairs; t += nshares) {
-                int I = 0;
-                while ((I + 1) * (I + 2) / 2 <= t) ++I;
-                if (cnt < SFB_PT - 1) ptab[w * SFB_PT + cnt] = (I << 8) | (t - I * (I + 1) / 2);
-                ++cnt;
-            }
+        for (int t = 1 + wp; t < npairs; t += nworkers) {
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= t) ++I;
+            if (cnt < SFB_PT - 1) ptab[w * SFB_PT + cnt] = (I << 8) | (t - I * (I + 1) / 2);
+            ++cnt;
         }
         ptab[w * SFB_PT + SFB_PT - 1] = cnt < SFB_PT ? cnt : SFB_PT - 1;
         if (cnt >= SFB_PT) sync[7] = 1;  // cannot happen for the window sizes the launcher admits
@@ -414,11 +411,12 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
         }
         const int xI0 = 1 + wpos, xI1 = 1 + wpos + nworkers;  // row blocks this wave solves (at most two)
         const int tabx = (xI0 < RB ? idxP(tl, xI0) : 0) | ((xI1 < RB ? idxP(tl, xI1) : 0) << 8);
-        int tabp = 0;  // band loaders: destination block of prefetch slot q when column slot `lane` retires
+        int tabp = 0;  // destination block of prefetch slot q when column slot `lane` retires
 #pragma unroll
         for (int q = 0; q < SFB_PF; ++q) {
             const int blk = pg + q * ngroups;
-            tabp |= (blk < nbr ? sfb_pair(tl, wrap(tl + 1 + blk)) : 0) << (8 * q);
+            tabp |= (band_loader ? (blk < nbr ? sfb_pair(tl, wrap(tl + 1 + blk)) : 0) : NBW + tl) << (8 * q);
+            if (band_loader && blk >= nbr) poff[q] = -1;
         }
         int arrivals = 0;
         auto worker_barrier = [&]() {
@@ -440,9 +438,8 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
                 if (xI1 == nb1 - 1 && kb > 0) spin_until(1, 4 * kb);
                 xsolve((wx >> 8) & 255, Fb2 + (kb & 1) * BS);
             }
-            if (wave == 1 && lane < BB) ld_acc += log(pv[(kb & 1) * BB + lane]);
             worker_barrier();
-            // ---- HBM prefetch of block row kb + nbr (lands after the updates)
+            // ---- HBM prefetch of block row kb + nbr (lands under the updates)
             if (kb + 1 < kend) {
                 // straight-line code: all loads are issued back to back, nothing here reads their results.
                 // Rows beyond the matrix (padding up to a multiple of 16) become identity rows; a bottom-up
@@ -473,6 +470,7 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
                     if (p + 1 < SFB_PT - 1 && p + 1 < mycnt) mma_store(pB, ldB, cB, aB, bB);
                 }
             }
+            if (wave == logwave && lane < BB) ld_acc += log(pv[(kb & 1) * BB + lane]);  // (its share of updates is the smallest)
             worker_barrier();
             if (wave == 1) publish(4, kb + 1);
             // ---- the prefetched rows land in the slots of column kb
@@ -480,12 +478,8 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
                 spin_until(3, kb + 1);
                 const int wp = __builtin_amdgcn_readlane(tabp, ks);
 #pragma unroll
-                for (int q = 0; q < SFB_PF; ++q) {
-                    const int blk = pg + q * ngroups;
-                    if (band_loader && blk >= nbr) continue;
-                    const int uni = band_loader ? ((wp >> (8 * q)) & 255) * BS : (NBW + ks) * BS;
-                    if (poff[q] >= 0) lds[uni + poff[q]] = pf[q];
-                }
+                for (int q = 0; q < SFB_PF; ++q)
+                    if (poff[q] >= 0) lds[((wp >> (8 * q)) & 255) * BS + poff[q]] = pf[q];
                 if (wave >= 4 && wave < 8) {  // group 0 holds block 0 = (new row, column kb+1) in its first register
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_fetch_add((lds_int_t*)&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -496,7 +490,7 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
     __syncthreads();
 
     // ---- outputs
-    if (wave == 1 && lane < BB) red[lane] = ld_acc;
+    if (wave == logwave && lane < BB) red[lane] = ld_acc;
     __syncthreads();
     double ldsum = 0.0;
     if (tid == 0) {
