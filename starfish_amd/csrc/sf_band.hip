@@ -15,26 +15,29 @@
 // (W+16) rows held in LDS.  The window is stored as 16 x 16 blocks addressed by the UNORDERED pair of
 // ring slots {row block % nbr, column block % nbr}: every live block of the lower triangle has its own
 // slot, nothing is ever shifted, and the footprint is nbr(nbr+1)/2 blocks instead of nbr^2.
-// Everything runs on v_mfma_f64_16x16x4_f64.  Per step k (columns 16k .. 16k+15), two barriers:
-//   X  the 16 band rows / right-hand-side columns that were prefetched from HBM into registers during
-//      the previous step land in the slots retired by column k-1; block column k+1 of the trailing
-//      update is applied (the wave that owns the newest row first solves it against L_kk);
-//   S  wave 0 factorises the diagonal block k+1 AND inverts its factor in the MFMA accumulator layout
-//      (one rank-1 MFMA per column each, pivots from scalars so that the rsqrt chain overlaps the
-//      matrix core) WHILE the other waves issue the next HBM prefetch, finish the trailing update and
-//      accumulate log(pivot); whoever is done waits on an LDS flag for the factor and solves its share
-//      of block column k+1 (X = P L^-T as a product with the explicit 16 x 16 inverse).
+// Everything runs on v_mfma_f64_16x16x4_f64.  Per step k (columns 16k .. 16k+15):
+//   wave 0   runs the sequential chain by itself, free of barriers: it factorises the diagonal block k AND
+//            inverts its factor in the MFMA accumulator layout (one rank-1 MFMA per column each, pivots from
+//            scalars so that the rsqrt chain overlaps the matrix core), publishes F_k = L_kk^-1, solves the
+//            next sub-diagonal block X_{k+1,k} = A_{k+1,k} F_k^T, applies it to the next diagonal block and
+//            goes on with k+1;
+//   waves 1+ ("workers") trail by one column: they solve the rest of block column k as products with F_k,
+//            apply column k to the window (software pipelined: operands of the next block are read under
+//            the MFMAs of the current one), fetch the next 16 band rows / right-hand-side columns from HBM
+//            into registers and drop them into the slots column k retires.
+// LDS flags order the two sides; the workers meet at two LDS-counter barriers per column.  Block addresses
+// depend on the ring phase k % nbr only: each wave tabulates its operations once (lane = phase) and reads
+// them back with one v_readlane per operation.
 // The right-hand sides (residual + the m rows of Y) ride along as extra ROWS of the matrix, so their
 // forward substitution is the same solve/update, and their Gram matrix [z Z]^T [z Z] accumulates in
 // LDS.  L is never written anywhere: the outputs are logdet(Bd) and the (1+m)^2 Gram matrix.
 // k_woodbury then does the m x m capacitance solve.
-// Measured on MI355X (cfg 2, W = 141 px, 16 waves): 1.5 ms for 128 matrices = one CU each; the
-// sequential diagonal-block chain (~5.5k cycles per step) and the per-CU fp64 MFMA rate (64 cycles
-// per 16x16x4, 55 blocks x 4 per step) bound it.  While 2*batch workgroups fit the chip the sweep is
-// therefore "twisted": one workgroup eliminates the first half of the columns top-down, a second one
-// the last half bottom-up (same code on the index-reversed matrix), both dump what is left of a
-// (W rounded up to 16)-row separator, k_band_merge adds the two Schur contributions and a short third
-// sweep finishes the separator: 0.89 ms instead of 1.52.
+// Measured on MI355X (cfg 2, W = 141 px, 16 waves): 1.27 ms for 128 matrices = one CU each (11.5k cycles
+// per column against 4.7k of MFMA time: 296 MFMAs x 64 cycles over four SIMDs).  While 2*batch workgroups
+// fit the chip the sweep is therefore "twisted": one workgroup eliminates the first half of the columns
+// top-down, a second one the last half bottom-up (same code on the index-reversed matrix), both dump what
+// is left of a (W rounded up to 16)-row separator, k_band_merge adds the two Schur contributions and a
+// short third sweep finishes the separator: 0.74 ms.
 #include "sf_common.h"
 #include <type_traits>
 
