@@ -904,7 +904,7 @@ __global__ __launch_bounds__(1024) void k_band_wide(sf_band_args a, double* __re
                 const double* lk = LK + (j - jlo) * BS + l15 * BLD + 4 * lq;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[0][kk], lk[kk], acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][kk], lk[kk], acc[u], 0, 0, 1);  // neg:[1,0,0]
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -939,8 +939,8 @@ __global__ __launch_bounds__(1024) void k_band_wide(sf_band_args a, double* __re
                     const double vn = sfb_readlane(v, qj * 16 + j + 1);
                     p = __builtin_fma(-vn, vn, an);
                 }
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, a0, 0, 0, 0);
-                f = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, g, f, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, a0, 0, 0, 1);  // neg:[1,0,0]
+                f = __builtin_amdgcn_mfma_f64_16x16x4f64(v, g, f, 0, 0, 1);
             }
             if (lane < BB) pv[(k & 1) * BB + lane] = pkeep;
             const unsigned long long neg = __ballot(lane < BB && !(pkeep > 0.0));

@@ -140,8 +140,8 @@ __device__ __forceinline__ void sf_syrk_diag_tile(const sf_gemm_args& g, int b, 
         for (int ks = 0; ks < GK / 4; ++ks) {
 #pragma unroll
             for (int q = 0; q < 5; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[bi[q] * 16 * GLD + ks * 4], S[bj[q] * 16 * GLD + ks * 4],
-                                                              acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[bi[q] * 16 * GLD + ks * 4], S[bj[q] * 16 * GLD + ks * 4],
+                                                              acc[q], 0, 0, 1);  // blgp 1 = neg:[1,0,0]: -A B + C
         }
     };
     for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -332,14 +332,14 @@ __global__ __launch_bounds__(NTH, (NTH == 256) ? 2 : NTH / 128) void k_gemm_nt(s
         for (int ks = 0; ks < GK / 4; ++ks) {
             double a[TM], bb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = NEG ? -Ab[i * 16 * GLD + ks * 4] : Ab[i * 16 * GLD + ks * 4];
+            for (int i = 0; i < TM; ++i) a[i] = Ab[i * 16 * GLD + ks * 4];
 #pragma unroll
             for (int i = 0; i < TN; ++i) bb[i] = Bb[i * 16 * GLD + ks * 4];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, NEG ? 1 : 0);  // the f64 MFMA's blgp bits negate: neg:[1,0,0]
         }
     };
     // steady state is ONE basic block: issue the next slab's global loads, run this slab's MFMAs from
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(1024) void k_diag_mfma(double* __restrict__ T, int6
                     const double a4[4] = {av[0][0].x, av[0][0].y, av[0][1].x, av[0][1].y};
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a4[kk], lk[kk], acc[u], 0, 0, 0);
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[kk], lk[kk], acc[u], 0, 0, 1);  // neg:[1,0,0]
 #pragma unroll
                     for (int d = 0; d < 3; ++d) {
                         av[d][0] = av[d + 1][0];
@@ -841,8 +841,8 @@ __global__ __launch_bounds__(1024) void k_diag_mfma(double* __restrict__ T, int6
                     const double vn = sf_readlane_d(v, qj * 16 + j + 1);
                     p = __builtin_fma(-vn, vn, an);
                 }
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, a0, 0, 0, 0);
-                f = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, g, f, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, a0, 0, 0, 1);  // neg:[1,0,0]
+                f = __builtin_amdgcn_mfma_f64_16x16x4f64(v, g, f, 0, 0, 1);
             }
             const unsigned long long neg = __ballot(lane < 16 && !(pkeep > 0.0));
             if (neg && !bad) bad = 16 * k + __ffsll((long long)neg);
