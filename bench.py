@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--npix", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--profile-steps", type=int, default=1,
+                    help="timed steps (the last ones) during which per-launch HIP events are recorded for `roofline`")
     ap.add_argument("--cpu-sample", type=int, default=8, help="walkers timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-structured", action="store_true", help="skip the banded-solver secondary figure")
     ap.add_argument("--no-cpu-pool", action="store_true", help="cpu_baseline: single-process mode only")
@@ -130,7 +132,6 @@ def main():
         do.loglike_device(md, P_dev, lnl, info)
     torch.cuda.synchronize()
     do.lib.sf_profile_read(None, None, None, None)
-    do.lib.sf_profile_enable(1)  # HIP events on the launch stream around every k_gemm_nt launch
     barrier()
     torch.cuda.synchronize()
     # one wave on its own stream samples the shader clock against the 100 MHz wall clock while the timed
@@ -141,8 +142,13 @@ def main():
     # main stream -- measured +40 ms on the timed region)
     if not use_dist and not os.environ.get("SF_BENCH_NO_CLOCK"):
         do.lib.sf_debug_clock_probe(D.ptr(clk), 4_000_000, C.c_void_p(clk_stream.cuda_stream))
+    # HIP events on the launch stream around every k_gemm_nt launch (and every stage) are recorded during the
+    # LAST `--profile-steps` of the timed steps: 148 event records per step cost 0.5 ms/step (0.9 %), measured
+    prof_steps = max(1, min(args.profile_steps, args.steps))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - prof_steps:
+            do.lib.sf_profile_enable(1)
         do.loglike_device(md, P_dev, lnl, info)
     torch.cuda.synchronize()
     barrier()
@@ -258,18 +264,19 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "note": "k_gemm_nt launches run on two streams (lookahead) and overlap: `achieved` divides by the "
-                "UNION of the launch intervals (HIP events, common origin); avg_launch_ms is the plain mean "
-                "launch duration (what rocprofv3 --stats reports)",
+                "UNION of the launch intervals (HIP events, common origin, recorded during the last `profiled_steps` of "
+                "the timed steps); avg_launch_ms is the plain mean launch duration (what rocprofv3 --stats reports)",
+                "profiled_steps": prof_steps,
                 "launches": int(glaunch.value),
                 "avg_launch_ms": ms[5] / max(1, glaunch.value),
                 "achieved_by_sum_of_launch_durations": gflops.value / (ms[5] * 1e-3) / 1e12 if ms[5] > 0 else None,
                 "algorithmic_flops_per_launch": gflops.value / max(1, glaunch.value),
             },
             "stage_ms_per_step": {
-                k: v / max(1, args.steps)
+                k: v / prof_steps
                 for k, v in zip(["transforms", "fill", "gemm_union", "potrf_stage", "solve", "gemm_launches_sum"], ms)
             },
-            "potrf_stage_tflops": B * args.steps * (N**3 / 3) / (ms[3] * 1e-3) / 1e12 if ms[3] > 0 else None,
+            "potrf_stage_tflops": B * prof_steps * (N**3 / 3) / (ms[3] * 1e-3) / 1e12 if ms[3] > 0 else None,
             "structured_solver": structured,
         }
         if world == 1 and args.cpu_sample > 0:
