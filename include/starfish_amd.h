@@ -51,6 +51,8 @@ extern "C" {
 #define SF_INFO_BAD_VSINI (-2)   /* vsini <= 0: transforms.py:121-122 */
 #define SF_INFO_BAD_WEIGHT_COV (-3) /* Sigma_w not positive definite: spectrum_model.py:334 */
 #define SF_INFO_BANDWIDTH (-4)   /* banded solver only: covariance support wider than the given half-width */
+#define SF_INFO_INTERNAL (-5)    /* banded solver only: a wave-synchronisation wait inside the sweep timed out;
+                                    cannot happen by construction (the bound keeps a logic error from hanging the GPU) */
 
 #define SF_JITTER 1e-10 /* spectrum_model.py:399 */
 

@@ -14,6 +14,7 @@ INFO_MESSAGES = {
     -2: "vsini must be positive",
     -3: "emulator weight covariance is not positive definite",
     -4: "covariance support wider than the band half-width given to the banded solver",
+    -5: "internal error: the banded sweep's wave synchronisation timed out (please report)",
 }
 INFO_BANDWIDTH = -4
 C_KMS = 2.99792458e5

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_band_forms(sf_band_args a) {
     double ldsum = 0.0;
     if (tid == 0) {
         for (int i = 0; i < BB; ++i) ldsum += red[i];
-        if (sync[7] && a.info) a.info[b] = -5;  // internal: pipeline flag wait timed out
+        if (sync[7] && a.info) a.info[b] = SF_INFO_INTERNAL;  // a pipeline flag wait timed out
         else if (bad && a.info && a.info[b] == 0) {
             // bottom-up half: report the column in the original numbering
             a.info[b] = half ? nblk * BB - bad + 1 : bad + a.info_off;
