@@ -86,9 +86,13 @@ __global__ __launch_bounds__(256) void k_tile_map(sf_fill_args a) {
     a.tilemap[(int64_t)b * nt * nt + e] = flag;
 }
 
-// Pass 1 (every stored tile): rank-m term on MFMA + sigma^2 on the diagonal + identity padding.
-// Lean on registers so that many waves hide the store latency (the pass is HBM-write bound).
-__global__ __launch_bounds__(256, 4) void k_fill_plain(sf_fill_args a, int nt, int jitter_here) {
+// Every stored tile in ONE pass: rank-m term on MFMA + sigma^2 on the diagonal + identity padding, and
+// (BAND) in the 32 x 32 sub-tiles that intersect the support of a structured kernel: + K_global, then
+// + (0 + K_local,0 + K_local,1 ...), then the jitter -- the reference's order of additions
+// (spectrum_model.py:338, 348, 353-363, 399).  Write-only: the pass is HBM-write bound (a separate band
+// pass used to read-modify-write the same tiles: 1.15 -> 0.5 ms at cfg 2).
+template <bool BAND>
+__global__ __launch_bounds__(256, BAND ? 2 : 4) void k_fill_tiles(sf_fill_args a, int nt) {
     const int id = sf_xcd_remap_f(blockIdx.x, gridDim.x);
     const int tiles = nt * nt;
     const int b = id / tiles;
@@ -129,11 +133,52 @@ __global__ __launch_bounds__(256, 4) void k_fill_plain(sf_fill_args a, int nt, i
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[j], brow[i], acc[i][j], 0, 0, 0);
     }
 
+    // which structured kernels reach this 32 x 32 sub-tile (wave-uniform)
+    bool do_glob = false;
+    double g_amp = 0, g_ls = 1, g_r0 = 0;
+    unsigned lmask = 0;
+    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
+    if (BAND && R0 < a.n && C0 < a.n) {
+        const int rlo = R0, rhi = min(R0 + 31, a.n - 1);
+        const int clo = C0, chi = min(C0 + 31, a.n - 1);
+        const bool on_diag = !(rlo > chi || clo > rhi);
+        if (a.has_global) {
+            g_amp = exp(P[a.off_global]);      // spectrum_model.py:343
+            g_ls = exp(P[a.off_global + 1]);   // spectrum_model.py:344
+            g_r0 = 6 * g_ls;                   // kernels.py:29
+            do_glob = true;
+            if (a.monotonic && !on_diag) {
+                // closest (row, col) pair of the sub-tile in wavelength
+                double wr, wc;
+                if (rlo > chi) { wr = a.wave[rlo]; wc = a.wave[chi]; }
+                else { wr = a.wave[rhi]; wc = a.wave[clo]; }
+                const double rmin = SF_C_KMS / 2 * fabs((wc - wr) / (wc + wr));
+                do_glob = rmin <= g_r0 * (1 + 1e-9);
+            }
+        }
+        for (int k = 0; k < a.n_local; ++k) {
+            bool hit = true;
+            if (a.monotonic) {
+                const double mu = P[a.off_local + 3 * k];
+                const double r0 = 4 * exp(P[a.off_local + 3 * k + 2]);  // kernels.py:73
+                auto dmin = [&](int lo, int hi) {  // smallest metric over an index range
+                    const double wl = a.wave[lo], wh = a.wave[hi];
+                    if (wl <= mu && mu <= wh) return 0.0;
+                    return fmin(sf_local_metric(wl, mu), sf_local_metric(wh, mu));
+                };
+                hit = (dmin(rlo, rhi) <= r0 * (1 + 1e-9)) && (dmin(clo, chi) <= r0 * (1 + 1e-9));
+            }
+            if (hit) lmask |= 1u << k;
+        }
+    }
+    const bool structured = do_glob || lmask;
+
     const bool vec_ok = (a.lda & 1) == 0;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
         const int row = R0 + ti * 16 + gam;
         if (row >= nout) continue;
+        const double w_row = (BAND && row < a.n) ? a.wave[row] : 1.0;
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
             const int col0 = C0 + tj * 16 + 4 * q;
@@ -147,12 +192,47 @@ __global__ __launch_bounds__(256, 4) void k_fill_plain(sf_fill_args a, int nt, i
                     if (row == col) {
                         const double sg = a.sigma[row];
                         val = val + sg * sg;                                     // spectrum_model.py:338
-                        if (jitter_here && a.add_jitter) val = val + SF_JITTER;  // spectrum_model.py:399
                     }
                 } else {
                     val = (row == col) ? 1.0 : 0.0;  // identity padding up to the Cholesky leaf
                 }
                 v[r] = val;
+            }
+            if (BAND && structured && row < a.n) {
+                double w_col[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w_col[r] = (col0 + r < a.n) ? a.wave[col0 + r] : 1.0;
+                if (do_glob && a.gtab) {  // log-uniform grid: one value per diagonal (see k_band_gtab)
+                    const double* gt = a.gtab + (int64_t)b * a.n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col0 + r < a.n) v[r] = v[r] + gt[abs(row - (col0 + r))];
+                } else if (do_glob) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col0 + r < a.n) v[r] = v[r] + sf_matern_elem(w_row, w_col[r], g_amp, g_ls, g_r0);
+                }
+                if (lmask) {
+                    double loc[4] = {0.0, 0.0, 0.0, 0.0};
+                    for (int k = 0; k < a.n_local; ++k) {
+                        if (!((lmask >> k) & 1)) continue;
+                        const double mu = P[a.off_local + 3 * k];
+                        const double amp = exp(P[a.off_local + 3 * k + 1]);  // spectrum_model.py:356
+                        const double sig = exp(P[a.off_local + 3 * k + 2]);  // spectrum_model.py:357
+                        const double d_row = sf_local_metric(w_row, mu);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            loc[r] = loc[r] + sf_local_elem(d_row, sf_local_metric(w_col[r], mu), amp, sig, 4 * sig);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col0 + r < a.n) v[r] = v[r] + loc[r];
+                }
+            }
+            if (a.add_jitter && row < a.n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col0 + r == row) v[r] = v[r] + SF_JITTER;  // spectrum_model.py:399
             }
             double* dst = Cb + (int64_t)row * a.lda + col0;
             if (vec_ok && col0 + 3 < nout) {
@@ -168,115 +248,6 @@ __global__ __launch_bounds__(256, 4) void k_fill_plain(sf_fill_args a, int nt, i
 }
 
 __global__ void k_band_gtab(sf_fill_args a, double* __restrict__ gtab, int ws);
-
-// Pass 2 (only sub-tiles that intersect the support of a structured kernel, everything else exits at
-// once): C += K_global, then C += (0 + K_local,0 + K_local,1 ...), then the jitter -- the reference's
-// order of additions (spectrum_model.py:348, 353-363, 399).
-__global__ __launch_bounds__(256) void k_fill_band(sf_fill_args a, int nt) {
-    const int id = sf_xcd_remap_f(blockIdx.x, gridDim.x);
-    const int tiles = nt * nt;
-    const int b = id / tiles;
-    const int t = id - b * tiles;
-    const int tm = t / nt, tn = t - tm * nt;
-    if (a.lower_only && tn > tm) return;
-    if (a.tilemap && !a.tilemap[(int64_t)b * a.nt128 * a.nt128 + (tm >> 1) * a.nt128 + (tn >> 1)]) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
-    if (R0 >= a.n || C0 >= a.n) return;
-    if (a.lower_only && C0 > R0 + 31) return;
-    const int gam = lane & 15, q = lane >> 4;
-    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
-    double* __restrict__ Cb = a.C + (int64_t)b * a.stride;
-
-    const int rlo = R0, rhi = min(R0 + 31, a.n - 1);
-    const int clo = C0, chi = min(C0 + 31, a.n - 1);
-    const bool on_diag = !(rlo > chi || clo > rhi);
-    bool do_glob = false;
-    double g_amp = 0, g_ls = 1, g_r0 = 0;
-    if (a.has_global) {
-        g_amp = exp(P[a.off_global]);      // spectrum_model.py:343
-        g_ls = exp(P[a.off_global + 1]);   // spectrum_model.py:344
-        g_r0 = 6 * g_ls;                   // kernels.py:29
-        do_glob = true;
-        if (a.monotonic && !on_diag) {
-            // closest (row, col) pair of the sub-tile in wavelength
-            double wr, wc;
-            if (rlo > chi) { wr = a.wave[rlo]; wc = a.wave[chi]; }
-            else { wr = a.wave[rhi]; wc = a.wave[clo]; }
-            const double rmin = SF_C_KMS / 2 * fabs((wc - wr) / (wc + wr));
-            do_glob = rmin <= g_r0 * (1 + 1e-9);
-        }
-    }
-    unsigned lmask = 0;
-    for (int k = 0; k < a.n_local; ++k) {
-        bool hit = true;
-        if (a.monotonic) {
-            const double mu = P[a.off_local + 3 * k];
-            const double r0 = 4 * exp(P[a.off_local + 3 * k + 2]);  // kernels.py:73
-            auto dmin = [&](int lo, int hi) {  // smallest metric over an index range
-                const double wl = a.wave[lo], wh = a.wave[hi];
-                if (wl <= mu && mu <= wh) return 0.0;
-                return fmin(sf_local_metric(wl, mu), sf_local_metric(wh, mu));
-            };
-            hit = (dmin(rlo, rhi) <= r0 * (1 + 1e-9)) && (dmin(clo, chi) <= r0 * (1 + 1e-9));
-        }
-        if (hit) lmask |= 1u << k;
-    }
-    const bool jitter = a.add_jitter && on_diag;
-    if (!do_glob && !lmask && !jitter) return;
-
-    const bool vec_ok = (a.lda & 1) == 0;
-    for (int ti = 0; ti < 2; ++ti) {
-        const int row = R0 + ti * 16 + gam;
-        if (row >= a.n) continue;
-        const double w_row = a.wave[row];
-        for (int tj = 0; tj < 2; ++tj) {
-            const int col0 = C0 + tj * 16 + 4 * q;
-            if (col0 >= a.n) continue;
-            double* dst = Cb + (int64_t)row * a.lda + col0;
-            const bool vec = vec_ok && col0 + 3 < a.n;
-            double v[4];
-            if (vec) {
-                const double2 p0 = *(const double2*)dst, p1 = *(const double2*)(dst + 2);
-                v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
-            } else {
-                for (int r = 0; r < 4; ++r) v[r] = (col0 + r < a.n) ? dst[r] : 0.0;
-            }
-            double w_col[4];
-            for (int r = 0; r < 4; ++r) w_col[r] = (col0 + r < a.n) ? a.wave[col0 + r] : 1.0;
-            if (do_glob && a.gtab) {  // log-uniform grid: one value per diagonal (see k_band_gtab)
-                const double* gt = a.gtab + (int64_t)b * a.n;
-                for (int r = 0; r < 4; ++r)
-                    if (col0 + r < a.n) v[r] = v[r] + gt[abs(row - (col0 + r))];
-            } else if (do_glob) {
-                for (int r = 0; r < 4; ++r) v[r] = v[r] + sf_matern_elem(w_row, w_col[r], g_amp, g_ls, g_r0);
-            }
-            if (lmask) {
-                double loc[4] = {0.0, 0.0, 0.0, 0.0};
-                for (int k = 0; k < a.n_local; ++k) {
-                    if (!((lmask >> k) & 1)) continue;
-                    const double mu = P[a.off_local + 3 * k];
-                    const double amp = exp(P[a.off_local + 3 * k + 1]);  // spectrum_model.py:356
-                    const double sig = exp(P[a.off_local + 3 * k + 2]);  // spectrum_model.py:357
-                    const double d_row = sf_local_metric(w_row, mu);
-                    for (int r = 0; r < 4; ++r)
-                        loc[r] = loc[r] + sf_local_elem(d_row, sf_local_metric(w_col[r], mu), amp, sig, 4 * sig);
-                }
-                for (int r = 0; r < 4; ++r) v[r] = v[r] + loc[r];
-            }
-            if (jitter)
-                for (int r = 0; r < 4; ++r)
-                    if (col0 + r == row) v[r] = v[r] + SF_JITTER;  // spectrum_model.py:399
-            if (vec) {
-                *(double2*)dst = make_double2(v[0], v[1]);
-                *(double2*)(dst + 2) = make_double2(v[2], v[3]);
-            } else {
-                for (int r = 0; r < 4; ++r)
-                    if (col0 + r < a.n) dst[r] = v[r];
-            }
-        }
-    }
-}
 
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
     if (a.n_local > SF_MAX_LOCAL) {
@@ -301,18 +272,15 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
         hipLaunchKernelGGL(k_band_gtab, dim3((a.n + 255) / 256, B), dim3(256), 0, s, a, a2.gtab, a.n - 1);
         SF_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_fill_plain, dim3((unsigned)nblk), dim3(256), 0, s, a, nt, structured ? 0 : 1);
+    if (structured) hipLaunchKernelGGL(k_fill_tiles<true>, dim3((unsigned)nblk), dim3(256), 0, s, a2, nt);
+    else hipLaunchKernelGGL(k_fill_tiles<false>, dim3((unsigned)nblk), dim3(256), 0, s, a2, nt);
     SF_LAUNCH_CHECK();
-    if (structured) {
-        hipLaunchKernelGGL(k_fill_band, dim3((unsigned)nblk), dim3(256), 0, s, a2, nt);
-        SF_LAUNCH_CHECK();
-    }
     return SF_OK;
 }
 
 // Band storage of Bd = diag(sigma^2) + K_global + sum K_local + jitter for the structure-exploiting
 // solver (sf_band.hip): band[i*ldb + d] = Bd[i][i-d], d in [0, ws).  The element formulas and their
-// order of additions are those of k_fill_band.  A thread on the last stored diagonal also probes the
+// order of additions are those of k_fill_tiles.  A thread on the last stored diagonal also probes the
 // first diagonal outside the storage: a non-zero there means the caller's half-width is too small
 // for this walker -> info = SF_INFO_BANDWIDTH (the result would silently drop covariance otherwise).
 // The element formulas are those of sf_matern_elem / sf_local_elem with the per-walker divisions
