@@ -689,12 +689,11 @@ int sf_launch_band_forms(const double* band, int n, int halfwidth, int ldb, int6
 static int launch_forms_kernel(const sf_band_args& a, int nrb, int nblocks, hipStream_t s) {
     const int nbr = a.nbr;
     const size_t shm = band_lds_bytes(nbr, nrb);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_seen = 0;  // devices whose function attributes are set
+    if (sf_first_use_on_device(&attr_seen)) {
         SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     // waves 4.. prefetch the band rows in groups of 256 threads (one 16 x 16 block per group and
     // register): enough groups for SFB_PF registers to cover the nbr blocks of a block row
@@ -1058,12 +1057,11 @@ int sf_launch_band_wide(double* band, int n, int halfwidth, int ldb, int64_t sba
     a.gram = gram;
     a.info = info;
     a.nhalf = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_seen = 0;  // devices whose function attributes are set
+    if (sf_first_use_on_device(&attr_seen)) {
         SF_HIP(hipFuncSetAttribute((const void*)k_band_wide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SF_HIP(hipFuncSetAttribute((const void*)k_band_wide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SF_HIP(hipFuncSetAttribute((const void*)k_band_wide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const size_t shm = band_wide_lds_bytes(wb, nrb);
     if (nrb == 1) hipLaunchKernelGGL(k_band_wide<1>, dim3(batch), dim3(1024), shm, s, a, work);

@@ -918,31 +918,34 @@ struct SideStream {
     std::vector<hipEvent_t> pool;
     size_t used = 0;
 };
-static SideStream g_side;
+static SideStream g_sides[64];   // one per device (multi-device processes: EchelleModel(devices=[...]))
+static SideStream* g_side_cur = &g_sides[0];  // the one of the device the current factorisation runs on
+static inline SideStream& side() { return *g_side_cur; }
 
 static int side_stream(hipStream_t* out) {
     int dev = 0;
     SF_HIP(hipGetDevice(&dev));
-    if (g_side.s == nullptr || g_side.device != dev) {
+    g_side_cur = &g_sides[(dev >= 0 && dev < 64) ? dev : 0];
+    if (side().s == nullptr || side().device != dev) {
         // highest priority: its small launches must win freed CU slots against the thousands of
         // pending MFMA workgroups of the main stream, otherwise the chain starves
         int prio_lo = 0, prio_hi = 0;
         SF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        SF_HIP(hipStreamCreateWithPriority(&g_side.s, hipStreamNonBlocking, prio_hi));
-        g_side.device = dev;
-        g_side.pool.clear();
+        SF_HIP(hipStreamCreateWithPriority(&side().s, hipStreamNonBlocking, prio_hi));
+        side().device = dev;
+        side().pool.clear();
     }
-    g_side.used = 0;
-    *out = g_side.s;
+    side().used = 0;
+    *out = side().s;
     return SF_OK;
 }
 static int next_event(hipEvent_t* e) {
-    if (g_side.used == g_side.pool.size()) {
+    if (side().used == side().pool.size()) {
         hipEvent_t ne;
         SF_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
-        g_side.pool.push_back(ne);
+        side().pool.push_back(ne);
     }
-    *e = g_side.pool[g_side.used++];
+    *e = side().pool[side().used++];
     return SF_OK;
 }
 #define SF_TRY(x)          \
@@ -1158,11 +1161,10 @@ int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int 
     const size_t fixed = sizeof(double) * (SF_LEAF * 65 + SF_LEAF + 8);
     const size_t with_z = fixed + sizeof(double) * (size_t)n;
     if (with_z <= 160 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
+        if (sf_first_use_on_device(&attr_seen)) {
             SF_HIP(hipFuncSetAttribute((const void*)k_trsv_logdet<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
         }
         hipLaunchKernelGGL(k_trsv_logdet<false>, dim3(batch), dim3(256), with_z, s, L, n, lda, stride, R,
                            ldr, (double*)nullptr, logdet, sqmah);

@@ -33,6 +33,17 @@ void sf_set_error(const char* fmt, ...);
 
 static inline size_t sf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Function attributes (dynamic LDS limit) are per device: `seen` is a per-call-site bitmask of the devices
+// that have been set up.  Returns true the first time the current device is seen.
+static inline bool sf_first_use_on_device(unsigned long long* seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const unsigned long long bit = 1ull << dev;
+    if (*seen & bit) return false;
+    *seen |= bit;
+    return true;
+}
+
 // profiling hooks (sf_abi.cpp)
 void sf_prof_gemm_begin(hipStream_t s, double flops, void** tok);
 void sf_prof_gemm_end(void* tok);

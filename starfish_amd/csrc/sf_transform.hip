@@ -902,13 +902,12 @@ static int launch_broaden_t(const sf_broaden_args& a, hipStream_t s) {
     const size_t shm = lds ? sizeof(double2) * (size_t)a.nf : 0;
     dim3 grid(a.rows, a.B);
     if (lds) {
-        static bool set = false;
-        if (!set) {
+        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
+        if (sf_first_use_on_device(&attr_seen)) {
             SF_HIP(hipFuncSetAttribute((const void*)k_broaden<true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             SF_HIP(hipFuncSetAttribute((const void*)k_broaden<false, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            set = true;
         }
         hipLaunchKernelGGL((k_broaden<FWD, true>), grid, dim3(256), shm, s, a.in, a.spec, a.rows, a.nf, a.tw,
                            a.dv, a.kind, a.params, a.pstride, a.poff, a.scalar_param, a.out, a.ob, a.orow,
@@ -935,11 +934,10 @@ static int launch_broaden_half(const sf_broaden_args& a, hipStream_t s) {
     const bool lds = (size_t)(a.nf / 2) <= kLdsFftMax;
     dim3 grid(a.rows, a.B);
     if (lds) {
-        static bool set = false;
-        if (!set) {
+        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
+        if (sf_first_use_on_device(&attr_seen)) {
             SF_HIP(hipFuncSetAttribute((const void*)k_broaden_half<true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            set = true;
         }
         hipLaunchKernelGGL(k_broaden_half<true>, grid, dim3(256), sizeof(double2) * (size_t)(a.nf / 2), s, a.spec,
                            a.mult, a.rows, a.nf, a.tw, a.kind, a.params, a.pstride, a.poff, a.scalar_param, a.out,
@@ -969,11 +967,10 @@ int sf_launch_rfft_rows(const double* in, int rows, int nf, const double2* tw, d
                         double2* gscratch, hipStream_t s) {
     const bool lds = (size_t)nf <= kLdsFftMax;
     if (lds) {
-        static bool set = false;
-        if (!set) {
+        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
+        if (sf_first_use_on_device(&attr_seen)) {
             SF_HIP(hipFuncSetAttribute((const void*)k_rfft_rows<true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            set = true;
         }
         hipLaunchKernelGGL(k_rfft_rows<true>, dim3(rows), dim3(256), sizeof(double2) * (size_t)nf, s, in, nf, tw,
                            spec, (double2*)nullptr);
