@@ -221,3 +221,18 @@ def test_band_halfwidth_bound_covers_the_true_support():
                       assert got <= true_hw + 4, (n, ls, sig, has_g, n_loc, true_hw, got)
     # a grid that is not strictly increasing cannot use the banded solver at all
     assert band_halfwidth_bound(wave[::-1], row, 3, 1, 1, 2)[0] == np.iinfo(np.int32).max
+
+
+def test_every_status_code_of_the_header_has_a_python_message():
+    """include/starfish_amd.h is the contract: each negative per-item status (SF_INFO_*) must be known to the
+    Python layer, which turns it into the reference's exceptions / messages."""
+    import re
+
+    from starfish_amd import _device as D
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "starfish_amd.h")).read()
+    codes = {name: int(val) for name, val in re.findall(r"#define\s+(SF_INFO_[A-Z_]+)\s+\((-\d+)\)", text)}
+    assert len(codes) >= 5, codes
+    for name, val in codes.items():
+        assert val in D.INFO_MESSAGES, (name, val)
+    assert D.INFO_BANDWIDTH == codes["SF_INFO_BANDWIDTH"]
