@@ -714,8 +714,8 @@ static int launch_forms_kernel(const sf_band_args& a, int nrb, int nblocks, hipS
 }
 
 // Two workgroups per matrix: top-down and bottom-up half sweeps meet at a separator of nm = 16*(nbr-1)
-// rows, which a third (short) sweep finishes.  Pays off while 2*batch workgroups still fit the chip:
-// the sweep is a sequential chain, so halving it halves the latency.  `work` needs
+// rows, which a third (short) sweep finishes.  Pays off while 2*batch workgroups still fit the chip (the
+// sweep is a sequential chain, so halving it halves the latency) and whenever it fills the rounds better.  `work` needs
 // sf_band_twisted_work_doubles(...) doubles.
 size_t sf_band_twisted_work_doubles(int halfwidth, int nrhs, int batch) {
     const size_t nbr = band_nbr(halfwidth), nm = (nbr - 1) * BB, nr = (size_t)((nrhs + BB - 1) / BB) * BB;
@@ -734,7 +734,15 @@ bool sf_band_twisted_applicable(int n, int halfwidth, int batch) {
     }
     static const bool off = getenv("SF_BAND_NO_TWIST") != nullptr;
     const int nbr = band_nbr(halfwidth), nblk = (n + BB - 1) / BB;
-    return !off && n % BB == 0 && 2 * batch <= ncu && nblk >= 6 * nbr;
+    if (off || n % BB != 0 || nblk < 6 * nbr) return false;
+    // One workgroup occupies a CU for the whole sweep, so the launch takes ceil(workgroups / CUs) rounds.
+    // Two half sweeps per matrix are half as long each but twice as many, plus merge and separator sweep
+    // (measured ~12 % of a sweep per round of matrices): take them when that means less time -- batch <=
+    // CUs/2, and again wherever the last round of single sweeps would be mostly empty (CUs < batch <=
+    // 1.5 CUs, ...).  Measured at cfg 2: B = 300: 2.37 -> 1.96 ms, 384: 2.34 -> 1.98, 640: 3.55 -> 3.25;
+    // B = 1600 (cfg 3 shape) stays with single sweeps (6.13 vs 6.39 ms).
+    const int rounds1 = (batch + ncu - 1) / ncu, rounds2 = (2 * batch + ncu - 1) / ncu;
+    return 0.5 * rounds2 + 0.12 * rounds1 < (double)rounds1;
 }
 
 int sf_launch_band_forms_twisted(const double* band, int n, int halfwidth, int ldb, int64_t sband, int batch,
