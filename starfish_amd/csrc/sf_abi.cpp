@@ -864,6 +864,26 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
 }
 
 // ------------------------------------------------------------------- structure-exploiting solver
+// Auxiliary stream of the banded path (one per device): work that does not depend on the main stream's
+// current stage runs there between a fork and a join event.
+struct AuxStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static int aux_stream(AuxStream** out) {
+    static AuxStream per_device[64];
+    int dev = 0;
+    SF_HIP(hipGetDevice(&dev));
+    AuxStream& a = per_device[(dev >= 0 && dev < 64) ? dev : 0];
+    if (!a.s) {
+        SF_HIP(hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking));
+        SF_HIP(hipEventCreateWithFlags(&a.fork, hipEventDisableTiming));
+        SF_HIP(hipEventCreateWithFlags(&a.join, hipEventDisableTiming));
+    }
+    *out = &a;
+    return SF_OK;
+}
+
 struct BandWork {
     double *band, *gram, *logdet_band, *twist, *gtab;
     int ldb;
@@ -925,15 +945,20 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
     BandWork bw = carve_band(c, mdl, B, halfwidth, d_work, work_bytes, base);
     g_prof.calls += 1;
     int rc;
-    {
-        ProfScope ps(s, PS_TRANSFORM);
-        rc = run_transforms(c, mdl, B, d_params, w, nullptr, nullptr, d_resid, d_log_scale, true, s);
-        if (rc) return rc;
+    // The band fill depends on the covariance hyper-parameters only, the transforms on the stellar ones:
+    // the two run side by side (fill on a library-owned auxiliary stream, joined before the sweep).
+    AuxStream* aux = nullptr;
+    rc = aux_stream(&aux);
+    if (rc) return rc;
+    hipStream_t sf = aux->s;
+    if (sf != s) {
+        SF_HIP(hipEventRecord(aux->fork, s));
+        SF_HIP(hipStreamWaitEvent(sf, aux->fork, 0));
     }
     const int64_t sband = (int64_t)c->npad * bw.ldb;
     {
-        ProfScope ps(s, PS_FILL);
-        SF_HIP(hipMemsetAsync(w.info_c, 0, sizeof(int) * (size_t)B, s));
+        ProfScope ps(sf, PS_FILL);
+        SF_HIP(hipMemsetAsync(w.info_c, 0, sizeof(int) * (size_t)B, sf));
         sf_fill_args f = fill_args(c, mdl, d_params, w);
         f.C = nullptr;
         f.lda = 0;
@@ -942,9 +967,16 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         f.add_jitter = 1;
         f.npad = (c->n + 15) / 16 * 16;
         const bool wide = halfwidth > sf_band_max_halfwidth(c->m + 1);
-        rc = sf_launch_band_fill(f, B, bw.band, wide ? bw.ldb : halfwidth + 1, bw.ldb, sband, w.info_c, bw.gtab, s);
+        rc = sf_launch_band_fill(f, B, bw.band, wide ? bw.ldb : halfwidth + 1, bw.ldb, sband, w.info_c, bw.gtab, sf);
         if (rc) return rc;
     }
+    if (sf != s) SF_HIP(hipEventRecord(aux->join, sf));
+    {
+        ProfScope ps(s, PS_TRANSFORM);
+        rc = run_transforms(c, mdl, B, d_params, w, nullptr, nullptr, d_resid, d_log_scale, true, s);
+        if (rc) return rc;
+    }
+    if (sf != s) SF_HIP(hipStreamWaitEvent(s, aux->join, 0));
     {
         ProfScope ps(s, PS_POTRF);
         const int n16 = (c->n + 15) / 16 * 16;
