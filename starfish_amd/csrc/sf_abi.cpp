@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -30,7 +32,8 @@ extern "C" int sf_device_count(void) {
 }
 
 // ----------------------------------------------------------------------------------- profiling
-// Global, single-threaded timing hooks for bench.py (HIP events on the caller's stream).
+// Process-global timing hooks for bench.py (HIP events on the launch streams), serialised by a mutex.
+// Nothing on the data path reads them.
 enum { PS_TRANSFORM = 0, PS_FILL, PS_GEMM, PS_POTRF, PS_SOLVE, PS_COUNT };
 struct ProfSpan {
     hipEvent_t a, b;
@@ -45,6 +48,7 @@ static struct {
     long calls = 0;
     hipEvent_t ref = nullptr;  // common time origin for merging overlapping launch intervals
 } g_prof;
+static std::mutex g_prof_mu;
 
 static hipEvent_t prof_event() {
     hipEvent_t e;
@@ -62,6 +66,7 @@ struct ProfScope {
     bool live;
     ProfScope(hipStream_t st, int stage) : s(st), live(g_prof.on != 0) {
         if (!live) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         sp.stage = stage;
         sp.a = prof_event();
         sp.b = prof_event();
@@ -69,6 +74,7 @@ struct ProfScope {
     }
     ~ProfScope() {
         if (!live) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         (void)hipEventRecord(sp.b, s);
         g_prof.spans.push_back(sp);
     }
@@ -78,15 +84,85 @@ void sf_prof_gemm_begin(hipStream_t s, double flops, void** tok) {
     *tok = nullptr;
     if (!g_prof.on) return;
     ProfScope* p = new ProfScope(s, PS_GEMM);
-    g_prof.gemm_flops += flops;
-    g_prof.gemm_launches += 1;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.gemm_flops += flops;
+        g_prof.gemm_launches += 1;
+    }
     *tok = p;
 }
 void sf_prof_gemm_end(void* tok) {
     if (tok) delete (ProfScope*)tok;
 }
 
+static void prof_count_call() {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.calls += 1;
+}
+
+// ----------------------------------------------------------------------------------- sf_exec
+int sf_exec_prepare(sf_exec* ex) {
+    int dev = 0;
+    SF_HIP(hipGetDevice(&dev));
+    if (ex->side == nullptr || ex->device != dev) {
+        if (ex->side) sf_exec_release(ex);
+        // highest priority: the small launches of the diagonal-block chain must win freed CU slots against
+        // the thousands of pending MFMA workgroups of the caller's stream, otherwise the chain starves
+        int prio_lo = 0, prio_hi = 0;
+        SF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        SF_HIP(hipStreamCreateWithPriority(&ex->side, hipStreamNonBlocking, prio_hi));
+        SF_HIP(hipStreamCreateWithFlags(&ex->aux, hipStreamNonBlocking));
+        SF_HIP(hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming));
+        SF_HIP(hipEventCreateWithFlags(&ex->join, hipEventDisableTiming));
+        ex->device = dev;
+    }
+    ex->used = 0;
+    return SF_OK;
+}
+int sf_exec_event(sf_exec* ex, hipEvent_t* e) {
+    if (ex->used == ex->pool_size) {
+        if (ex->pool_size == ex->pool_cap) {
+            const size_t cap = ex->pool_cap ? 2 * ex->pool_cap : 256;
+            hipEvent_t* np = (hipEvent_t*)realloc(ex->pool, cap * sizeof(hipEvent_t));
+            if (!np) {
+                sf_set_error("out of host memory (event pool)");
+                return SF_ENOMEM;
+            }
+            ex->pool = np;
+            ex->pool_cap = cap;
+        }
+        hipEvent_t ne;
+        SF_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+        ex->pool[ex->pool_size++] = ne;
+    }
+    *e = ex->pool[ex->used++];
+    return SF_OK;
+}
+void sf_exec_release(sf_exec* ex) {
+    if (!ex) return;
+    for (size_t i = 0; i < ex->pool_size; ++i) (void)hipEventDestroy(ex->pool[i]);
+    free(ex->pool);
+    ex->pool = nullptr;
+    ex->pool_size = ex->pool_cap = ex->used = 0;
+    if (ex->fork) (void)hipEventDestroy(ex->fork);
+    if (ex->join) (void)hipEventDestroy(ex->join);
+    if (ex->side) (void)hipStreamDestroy(ex->side);
+    if (ex->aux) (void)hipStreamDestroy(ex->aux);
+    ex->fork = ex->join = nullptr;
+    ex->side = ex->aux = nullptr;
+    ex->device = -1;
+}
+// context-free entry points (sf_potrf_batch, ...): one sf_exec per calling thread and device
+sf_exec* sf_exec_thread_local(void) {
+    static thread_local sf_exec per_device[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return &per_device[(dev >= 0 && dev < 64) ? dev : 0];
+}
+
 extern "C" int sf_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.on = on;
     if (on) {
         if (!g_prof.ref) SF_HIP(hipEventCreate(&g_prof.ref));
@@ -95,6 +171,7 @@ extern "C" int sf_profile_enable(int on) {
     return SF_OK;
 }
 extern "C" int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches, long* calls) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     double acc[PS_COUNT + 1] = {0, 0, 0, 0, 0, 0};
     std::vector<std::pair<double, double>> gemm_iv;  // [start, end) of every MFMA launch, ms since ref
     for (auto& sp : g_prof.spans) {
@@ -291,6 +368,8 @@ struct sf_ctx {
     double dv = 0.0, wave_max = 0.0;
     DevBuf wave, flux, sigma, knots, spec, tw, Lf, Uf, rdiag, coef_static, inv_band;
     DevBuf grid, variances, lengthscales, gmin, gmax, alpha, Linv;
+    sf_exec exec;  // side / auxiliary streams and the event pool of this context's launch sequences
+    ~sf_ctx() { sf_exec_release(&exec); }
 };
 
 static double min_dv(const double* w, int n) {  // Starfish/utils.py:22
@@ -508,6 +587,11 @@ static int model_ok(const sf_ctx* c, const sf_model_desc* mdl) {
         sf_set_error("bad context / model descriptor");
         return SF_EINVAL;
     }
+    return SF_OK;
+}
+// the calling thread's current device becomes the context's (HIP's current device is per thread)
+static int use_device(const sf_ctx* c) {
+    SF_HIP(hipSetDevice(c->device));
     return SF_OK;
 }
 extern "C" int sf_param_stride(const sf_ctx* c, const sf_model_desc* mdl) {
@@ -735,7 +819,7 @@ static int check_work(const sf_ctx* c, const sf_model_desc* mdl, int B, const vo
         sf_set_error("workspace too small: have %zu, need %zu", have, need);
         return SF_ENOMEM;
     }
-    return SF_OK;
+    return use_device(c);
 }
 
 extern "C" int sf_emulator_query_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params,
@@ -818,7 +902,7 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
     }
     hipStream_t s = (hipStream_t)stream;
     Work w = carve(c, mdl, B, d_work, work_bytes, true);
-    g_prof.calls += 1;
+    prof_count_call();
     const int64_t stride = (int64_t)c->npad * c->lda;
     {
         ProfScope ps(s, PS_TRANSFORM);
@@ -848,7 +932,7 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
         gen.ldy = c->npad;
         gen.tilemap = w.tilemap;
         gen.nt128 = (c->npad + 127) / 128;
-        rc = sf_launch_potrf(w.C, c->npad, c->lda, stride, B, w.info_c, w.ltbuf, w.resid, c->npad, s, &gen);
+        rc = sf_launch_potrf(w.C, c->npad, c->lda, stride, B, w.info_c, w.ltbuf, w.resid, c->npad, s, &gen, &c->exec);
         if (rc) return rc;
     }
     {
@@ -864,26 +948,6 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
 }
 
 // ------------------------------------------------------------------- structure-exploiting solver
-// Auxiliary stream of the banded path (one per device): work that does not depend on the main stream's
-// current stage runs there between a fork and a join event.
-struct AuxStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static int aux_stream(AuxStream** out) {
-    static AuxStream per_device[64];
-    int dev = 0;
-    SF_HIP(hipGetDevice(&dev));
-    AuxStream& a = per_device[(dev >= 0 && dev < 64) ? dev : 0];
-    if (!a.s) {
-        SF_HIP(hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking));
-        SF_HIP(hipEventCreateWithFlags(&a.fork, hipEventDisableTiming));
-        SF_HIP(hipEventCreateWithFlags(&a.join, hipEventDisableTiming));
-    }
-    *out = &a;
-    return SF_OK;
-}
-
 struct BandWork {
     double *band, *gram, *logdet_band, *twist, *gtab;
     int ldb;
@@ -941,16 +1005,17 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         return SF_ENOMEM;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (use_device(c)) return SF_EHIP;
     Work w = carve(c, mdl, B, d_work, work_bytes, false);
     BandWork bw = carve_band(c, mdl, B, halfwidth, d_work, work_bytes, base);
-    g_prof.calls += 1;
+    prof_count_call();
     int rc;
     // The band fill depends on the covariance hyper-parameters only, the transforms on the stellar ones:
     // the two run side by side (fill on a library-owned auxiliary stream, joined before the sweep).
-    AuxStream* aux = nullptr;
-    rc = aux_stream(&aux);
+    sf_exec* aux = &c->exec;
+    rc = sf_exec_prepare(aux);
     if (rc) return rc;
-    hipStream_t sf = aux->s;
+    hipStream_t sf = aux->aux;
     if (sf != s) {
         SF_HIP(hipEventRecord(aux->fork, s));
         SF_HIP(hipStreamWaitEvent(sf, aux->fork, 0));

@@ -725,13 +725,14 @@ __device__ __forceinline__ double sfd_rsqrt(double p) {
     return y;
 }
 
-__global__ __launch_bounds__(1024) void k_diag_mfma(double* __restrict__ T, int64_t sT, int pw,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_diag_mfma(double* __restrict__ T, int64_t sT, int pw,
                                                       int* __restrict__ info, int info_off,
                                                       double* __restrict__ rhs, int ldr,
                                                       double* __restrict__ Cdiag, int ldc, int64_t sC,
                                                       double* __restrict__ Wt, int64_t sW) {
-    __shared__ double LK[15 * DBS];  // L(k, j), j < k: the B operand of the whole block column
-    __shared__ double ST[16 * DBS];  // per-wave staging block (accumulator layout -> operand layout)
+    __shared__ double LK[(NT / 64 - 1) * DBS];  // L(k, j), j < k: the B operand of the whole block column
+    __shared__ double ST[(NT / 64) * DBS];      // per-wave staging block (accumulator layout -> operand layout)
     __shared__ double Fb[DBS];       // inverse of the current 16 x 16 diagonal factor
     __shared__ double rz[256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(1024) void k_diag_mfma(double* __restrict__ T, int6
     double* st = ST + wave * DBS;
 
     // Wt is lower triangular: zero the blocks above the diagonal (the buffer alternates between panels)
-    for (int e = tid; e < nb * nb * 256; e += 1024) {
+    for (int e = tid; e < nb * nb * 256; e += NT) {
         const int blk = e >> 8, bc = blk / nb, be = blk - bc * nb;
         if (be > bc) Wb[(int64_t)(bc * 16 + ((e >> 4) & 15)) * SF_LDT + be * 16 + (e & 15)] = 0.0;
     }
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(1024) void k_diag_mfma(double* __restrict__ T, int6
     for (int k = 0; k < nb; ++k) {
         const int m = nb - 1 - k;  // matrix row blocks below the diagonal block
         // ---- stage L(k, 0..k-1) (final since the previous columns) in LDS
-        for (int e = tid; e < k * 256; e += 1024) {
+        for (int e = tid; e < k * 256; e += NT) {
             const int j = e >> 8, r = (e >> 4) & 15, cc = e & 15;
             LK[j * DBS + r * DLD + cc] = Tb[(int64_t)(16 * k + r) * SF_LDT + 16 * j + cc];
         }
@@ -888,9 +889,9 @@ __global__ __launch_bounds__(1024) void k_diag_mfma(double* __restrict__ T, int6
     // ---- z_k = L_kk^-1 r_k with the explicit inverse
     if (rhs) {
         double* rb = rhs + (int64_t)b * ldr;
-        for (int i = tid; i < pw; i += 1024) rz[i] = rb[i];
+        for (int i = tid; i < pw; i += NT) rz[i] = rb[i];
         __syncthreads();
-        for (int i = tid; i < pw; i += 1024) {
+        for (int i = tid; i < pw; i += NT) {
             const double* wrow = Wb + (int64_t)i * SF_LDT;
             double zacc = 0.0;
             for (int j = 0; j <= i; ++j) zacc = __builtin_fma(wrow[j], rz[j], zacc);
@@ -899,6 +900,355 @@ __global__ __launch_bounds__(1024) void k_diag_mfma(double* __restrict__ T, int6
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused left-looking panel step (panel width = tile edge = 128).  One workgroup owns a 128-row slab
+// of the panel [k0, k0 + pw) and does, without leaving the CU:
+//   1  T  = C[slab, panel] - L[slab, :k0] L[panel rows, :k0]^T          long K, the k_gemm_nt main loop
+//   2  L  = T W,  W = L_kk^-T (Wt = L_kk^-1 from k_diag_mfma)           K = pw, triangular
+//   3  L -> C[slab, panel] in place;  rhs[slab] -= L z_k                (forward substitution rides along)
+//   4  S  = C[slab, slab] - L L^T                                       K = pw, lower triangle only
+// Steps 2 and 4 take their A operand from the accumulators through LDS (32-column chunks): the panel
+// scratch T of the unfused scheme is never written or read back, and the short-K launches G and R
+// (0.3 of peak, all tiles of a round in the same memory phase) are gone.  In step 2 the chunks are
+// visited in DESCENDING k order: L block columns need exactly the chunks up to their own, so a wave
+// dumps a T block at the moment its registers become the accumulators of the L block -- no second
+// accumulator set.  Step 4 uses the 36-blocks-on-8-waves layout of sf_syrk_diag_tile.
+// pw == 0: nothing but the copy of the diagonal tile to Sout (start of the factorisation).
+#define CLD 33  // row stride (doubles) of the 128 x 32 chunk buffer
+struct sf_panel_args {
+    double* C;
+    int64_t sC;
+    int lda, n;
+    int k0, pw;       // panel columns [k0, k0 + pw), pw in {0, 64, 128}
+    int row0, nslab;  // slabs of 128 rows starting at row0 (multiple of 128); the last one may be shorter
+    const double* Wt; // [batch] x sW: Wt[c][k] = (L_kk^-1)[c][k], row stride SF_LDT
+    int64_t sW;
+    double* rhs;      // [batch] x ldr or NULL
+    int ldr;
+    double* Sout;     // updated diagonal tile goes here (row stride ldS) instead of in place when non-NULL
+    int64_t sS;
+    int ldS;
+    const double* genY;  // matrix-free start (see sf_gemm_args)
+    const unsigned char* tilemap;
+    int64_t sY;
+    int ldy, mpad, nt128;
+};
+
+template <bool RHS>
+__global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
+    constexpr int TM = 2, TN = 4;
+    __shared__ __attribute__((aligned(16))) double sm[4 * GT * GLD];
+    __shared__ double red[2][GT];
+    double(*As)[GT * GLD] = (double(*)[GT * GLD]) sm;
+    double(*Bs)[GT * GLD] = (double(*)[GT * GLD])(sm + 2 * GT * GLD);
+    double* Ach = sm;  // 128 x CLD chunk buffer of the epilogue (aliases As)
+
+    const int id = sf_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = id / g.nslab;
+    const int sl = id - b * g.nslab;
+    const int row0 = g.row0 + sl * GT;
+    const int rows_here = min(GT, g.n - row0);
+    const int pw = g.pw, k0 = g.k0;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;  // rows wm*32.., cols wn*64..
+    const int l15 = lane & 15, lq = lane >> 4;
+    double* Cb = g.C + (int64_t)b * g.sC;
+
+    sf_d4 acc[TM][TN];
+    if (pw > 0) {
+        // ---------------------------------------------------------------- 1: long-K update
+        const int lr = tid >> 3, lc = (tid & 7) * 2;
+        const double* Ap[2];
+        const double* Bp[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            Ap[p] = Cb + (int64_t)(row0 + min(lr + 64 * p, rows_here - 1)) * g.lda + lc;
+            Bp[p] = Cb + (int64_t)(k0 + min(lr + 64 * p, pw - 1)) * g.lda + lc;
+        }
+        double2 ra[2], rb[2];
+        auto gload = [&](int kt) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                ra[p] = *(const double2*)(Ap[p] + kt * GK);
+                rb[p] = *(const double2*)(Bp[p] + kt * GK);
+            }
+        };
+        auto lstore = [&](int buf) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                double* pa = &As[buf][(lr + 64 * p) * GLD + lc];
+                double* pb = &Bs[buf][(lr + 64 * p) * GLD + lc];
+                pa[0] = ra[p].x;
+                pa[1] = ra[p].y;
+                pb[0] = rb[p].x;
+                pb[1] = rb[p].y;
+            }
+        };
+        const int nk = k0 / GK;
+        if (nk > 0) gload(0);
+
+        bool generate = false;
+        if (g.tilemap) generate = !g.tilemap[(int64_t)b * g.nt128 * g.nt128 + (row0 / GT) * g.nt128 + k0 / GT];
+        if (generate) {
+            const double* Yb = g.genY + (int64_t)b * g.sY;
+            const int gr = row0 + wm * (16 * TM) + l15;
+            const int gc = k0 + wn * (16 * TN) + l15;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+            for (int kk = 0; kk < g.mpad; kk += 4) {
+                const double* yk = Yb + (int64_t)(kk + lq) * g.ldy;
+                double ya[TM], yb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ya[i] = yk[min(gr + i * 16, g.ldy - 1)];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) yb[i] = yk[min(gc + i * 16, g.ldy - 1)];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[mi], yb[ni], acc[mi][ni], 0, 0, 0);
+            }
+        } else {
+            const double* Cin = Cb + (int64_t)row0 * g.lda + k0;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int col = wn * (16 * TN) + ni * 16 + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = wm * (16 * TM) + mi * 16 + lq + 4 * r;
+                        double v = 0.0;
+                        if (row < rows_here && col < pw) v = Cin[(int64_t)row * g.lda + col];
+                        acc[mi][ni][r] = v;
+                    }
+                }
+        }
+        if (nk > 0) lstore(0);
+        __syncthreads();
+        auto compute = [&](int cur) {
+            const double* Ab = &As[cur][(wm * (16 * TM) + l15) * GLD + lq];
+            const double* Bb = &Bs[cur][(wn * (16 * TN) + l15) * GLD + lq];
+#pragma unroll
+            for (int ks = 0; ks < GK / 4; ++ks) {
+                double a[TM], bb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = Ab[i * 16 * GLD + ks * 4];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) bb[i] = Bb[i * 16 * GLD + ks * 4];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, 1);  // neg:[1,0,0]
+            }
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            gload(kt + 1);
+            compute(kt & 1);
+            lstore((kt & 1) ^ 1);
+            __syncthreads();
+        }
+        if (nk > 0) compute((nk - 1) & 1);
+
+        // ---------------------------------------------------------------- 2: L = T W through LDS
+        const int nsb = pw >> 4;  // 16-column blocks of the panel (4 or 8)
+        const double* Wp[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            Wp[p] = g.Wt + (int64_t)b * g.sW + (int64_t)min(lr + 64 * p, pw - 1) * SF_LDT + lc;
+        double2 rw[2];
+        auto wload = [&](int sb) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) rw[p] = *(const double2*)(Wp[p] + sb * 16);
+        };
+        auto wstore = [&](int buf) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                double* pb = &Bs[buf][(lr + 64 * p) * GLD + lc];
+                pb[0] = rw[p].x;
+                pb[1] = rw[p].y;
+            }
+        };
+        // dump the two 16-column blocks of chunk q that this wave owns (accumulator -> operand layout)
+        auto dump = [&](int q, bool zero) {
+            if (wn != (q >> 1)) return;
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (half != (q & 1)) continue;
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            Ach[(wm * (16 * TM) + mi * 16 + lq + 4 * r) * CLD + nn * 16 + l15] = acc[mi][2 * half + nn][r];
+                        if (zero) acc[mi][2 * half + nn] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+                    }
+                }
+        };
+        wload(nsb - 1);
+        int buf = 0;
+        // (fully unrolled: chunk and block indices are compile-time constants, only wave-uniform branches remain)
+#pragma unroll
+        for (int sbi = 0; sbi < GT / 16; ++sbi) {
+            const int sb = GT / 16 - 1 - sbi;
+            if (sb >= nsb) continue;  // narrow last panel
+            if (sb & 1) {  // first block of chunk sb / 2 in descending order
+                __syncthreads();  // everybody is done with the previous contents of the chunk buffer / As
+                dump(sb >> 1, true);
+            }
+            wstore(buf);
+            __syncthreads();
+            if (sb > 0) wload(sb - 1);
+            // W[k][c] = 0 for k > c: this wave's 64 columns need the blocks k <= 4 wn + 3 only (one wave-uniform
+            // branch around a straight-line body; inside it the zero blocks of W are multiplied through, which
+            // leaves the not-yet-dumped T blocks and the finished sums bit-for-bit unchanged)
+            if (sb <= wn * TN + (TN - 1)) {
+                const double* Ab = &Ach[(wm * (16 * TM) + l15) * CLD + (sb & 1) * 16 + lq];
+                const double* Bb = &Bs[buf][(wn * (16 * TN) + l15) * GLD + lq];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    double a[TM], bb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = Ab[i * 16 * CLD + ks * 4];
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) bb[i] = Bb[i * 16 * GLD + ks * 4];
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+
+        // ---------------------------------------------------------------- 3: L in place, rhs -= L z
+        double* Lout = Cb + (int64_t)row0 * g.lda + k0;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = wn * (16 * TN) + ni * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * (16 * TM) + mi * 16 + lq + 4 * r;
+                    if (row < rows_here && col < pw) Lout[(int64_t)row * g.lda + col] = acc[mi][ni][r];
+                }
+            }
+        if (RHS && g.rhs) {
+            const double* z = g.rhs + (int64_t)b * g.ldr + k0;
+            double zc[TN];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = wn * (16 * TN) + ni * 16 + l15;
+                zc[ni] = col < pw ? z[col] : 0.0;
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) v = __builtin_fma(acc[mi][ni][r], zc[ni], v);
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    if (l15 == 0) red[wn][wm * (16 * TM) + mi * 16 + lq + 4 * r] = v;
+                }
+        }
+    }
+
+    // -------------------------------------------------------------------- 4: S = C[slab, slab] - L L^T
+    // 36 lower blocks on 8 waves (5 + 4 per wave pair, see sf_syrk_diag_tile) in two passes of 3 + 2 blocks per
+    // wave: the L accumulators stay live while their chunks are dumped, 5 more blocks do not fit the budget
+    {
+        const int p = w >> 1, h = w & 1;
+        const int nch = pw >> 5;
+        const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
+        double* So = g.Sout ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
+        const int ldo = g.Sout ? g.ldS : g.lda;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            constexpr int NQ = 3;
+            const int nq = pass ? 2 : 3, q0 = pass ? 3 : 0;
+            int bi[NQ], bj[NQ];
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) {
+                const int q = q0 + (qq < nq ? qq : 0);
+                if (h == 0) {
+                    bi[qq] = 7 - p;
+                    bj[qq] = q;
+                } else {
+                    const int n_hi = 3 - p;  // blocks 5 .. 7-p of row 7-p, then blocks 0 .. p of row p
+                    const int qx = q < 4 ? q : 0;
+                    bi[qq] = qx < n_hi ? 7 - p : p;
+                    bj[qq] = qx < n_hi ? 5 + qx : qx - n_hi;
+                }
+            }
+            const int nstore = (h == 1 && pass == 1) ? 1 : nq;  // (h == 1 owns 4 blocks: q = 4 is a spare)
+            sf_d4 acc2[NQ];
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bi[qq] + lq + 4 * r, col = 16 * bj[qq] + l15;
+                    acc2[qq][r] = (qq < nstore && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
+                }
+#pragma unroll
+            for (int q = 0; q < GT / 32; ++q) {
+                if (q >= nch) continue;
+                __syncthreads();
+                if (wn == (q >> 1)) {  // chunk q of L (columns 32 q ..) from the accumulators of its owner waves
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        if (half != (q & 1)) continue;
+#pragma unroll
+                        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    Ach[(wm * (16 * TM) + mi * 16 + lq + 4 * r) * CLD + nn * 16 + l15] =
+                                        acc[mi][2 * half + nn][r];
+                    }
+                }
+                __syncthreads();
+                const double* S = &Ach[l15 * CLD + lq];
+#pragma unroll 2
+                for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                    for (int qq = 0; qq < NQ; ++qq) {
+                        if (qq >= nq) continue;
+                        acc2[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[bi[qq] * 16 * CLD + ks * 4], S[bj[qq] * 16 * CLD + ks * 4],
+                                                                        acc2[qq], 0, 0, 1);  // neg:[1,0,0]
+                    }
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) {
+                if (qq >= nstore) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bi[qq] + lq + 4 * r, col = 16 * bj[qq] + l15;
+                    if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[qq][r];
+                }
+            }
+        }
+    }
+    if (RHS && g.rhs && pw > 0) {
+        __syncthreads();
+        if (tid < rows_here) g.rhs[(int64_t)b * g.ldr + row0 + tid] -= red[0][tid] + red[1][tid];
+    }
+}
 
 // The per-matrix scratch strides are skewed by a few hundred bytes: with strides that are multiples of
 // 32 KiB every workgroup of the batch touches the same HBM channel / L2 bank at the same time (measured:
@@ -910,44 +1260,9 @@ size_t sf_potrf_work_doubles(int n, int batch) {
 }
 
 // ---- two-stream lookahead ---------------------------------------------------------------------
-// The diagonal-block chain (D) is a sequence of small latency-bound launches; it runs on a library
-// owned side stream concurrently with the big MFMA launches of the main stream.
-struct SideStream {
-    int device = -1;
-    hipStream_t s = nullptr;
-    std::vector<hipEvent_t> pool;
-    size_t used = 0;
-};
-static SideStream g_sides[64];   // one per device (multi-device processes: EchelleModel(devices=[...]))
-static SideStream* g_side_cur = &g_sides[0];  // the one of the device the current factorisation runs on
-static inline SideStream& side() { return *g_side_cur; }
-
-static int side_stream(hipStream_t* out) {
-    int dev = 0;
-    SF_HIP(hipGetDevice(&dev));
-    g_side_cur = &g_sides[(dev >= 0 && dev < 64) ? dev : 0];
-    if (side().s == nullptr || side().device != dev) {
-        // highest priority: its small launches must win freed CU slots against the thousands of
-        // pending MFMA workgroups of the main stream, otherwise the chain starves
-        int prio_lo = 0, prio_hi = 0;
-        SF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        SF_HIP(hipStreamCreateWithPriority(&side().s, hipStreamNonBlocking, prio_hi));
-        side().device = dev;
-        side().pool.clear();
-    }
-    side().used = 0;
-    *out = side().s;
-    return SF_OK;
-}
-static int next_event(hipEvent_t* e) {
-    if (side().used == side().pool.size()) {
-        hipEvent_t ne;
-        SF_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
-        side().pool.push_back(ne);
-    }
-    *e = side().pool[side().used++];
-    return SF_OK;
-}
+// The diagonal-block chain is a sequence of small latency-bound launches; it runs on the side stream of
+// the caller's sf_exec (owned by the context or by the calling thread) concurrently with the big MFMA
+// launches of the caller's stream.
 #define SF_TRY(x)          \
     do {                   \
         int rc__ = (x);    \
@@ -968,8 +1283,8 @@ static int next_event(hipEvent_t* e) {
 // Lookahead (two streams): only the rows of the NEXT diagonal block are on the critical chain.
 //   side:  D(k) F(k) | wait Ur(k) | Gt(k) Rnext(k -> k+1) | D(k+1) ...
 //   main:  wait Gt(k-1) | Ur(k) | wait F(k) | Gr(k) Rrest(k) | ...
-int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
-                    double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen) {
+static int sf_launch_potrf_v1(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
+                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
     if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
         sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
         return SF_EINVAL;
@@ -981,8 +1296,9 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     const int64_t sW = (int64_t)SF_NB * SF_LDT + SF_TSKEW;
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
 
-    hipStream_t c = nullptr;  // side ("critical chain") stream
-    SF_TRY(side_stream(&c));
+    SF_TRY(sf_exec_prepare(ex));
+    hipStream_t c = ex->side;  // side ("critical chain") stream
+    auto next_event = [&](hipEvent_t* e) { return sf_exec_event(ex, e); };
     static const bool no_lookahead = getenv("SF_NO_LOOKAHEAD") != nullptr;  // tuning aid: single stream
     static const int rlazy = getenv("SF_RLAZY") ? atoi(getenv("SF_RLAZY")) : 1;  // tuning aid; measured: no gain for 2, 4, 8
     if (no_lookahead) c = s;
@@ -1068,7 +1384,7 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
         // ---- D + F on the side stream (T rows [0, pw) already hold the fully updated diagonal block)
         static const bool leaf_diag = getenv("SF_LEAF_DIAG") != nullptr;  // tuning aid: the 13-launch chain
         if (!leaf_diag) {
-            hipLaunchKernelGGL(k_diag_mfma, dim3(batch), dim3(1024), 0, c, T, sT, pw, info, k0,
+            hipLaunchKernelGGL(k_diag_mfma<1024>, dim3(batch), dim3(1024), 0, c, T, sT, pw, info, k0,
                                rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
             SF_LAUNCH_CHECK();
         } else {
@@ -1150,6 +1466,121 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     SF_HIP(hipEventRecord(e_join, c));
     SF_HIP(hipStreamWaitEvent(s, e_join, 0));
     return SF_OK;
+}
+
+// Factorisation with the fused panel kernel (default).  Panels of 128 columns; per panel k
+//   D(k)      k_diag_mfma on the updated diagonal tile (parked in the scratch T): L_kk, L_kk^-1, z_k
+//   top(k)    k_chol_panel for the slab of the NEXT diagonal tile (rows k1 .. k1+128): its updated tile goes to T
+//   rest(k)   k_chol_panel for all slabs below
+// Lookahead on two streams: side  D(k) -> [wait rest(k-1)] top(k) -> D(k+1) ...
+//                           main  [wait D(k)] rest(k) ...
+// rest(k) only needs D(k), which ran beside rest(k-1); top(k) needs the rows rest(k-1) finished.
+static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
+                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
+    if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
+        sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
+        return SF_EINVAL;
+    }
+    double* T = work + (size_t)batch * SF_LTB_DOUBLES;
+    const int64_t sT = (int64_t)(n + SF_NB) * SF_LDT + SF_TSKEW;  // (layout shared with the unfused path)
+    double* Wt2 = T + (size_t)batch * sT;
+    const int64_t sW = (int64_t)SF_NB * SF_LDT + SF_TSKEW;
+    SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
+    SF_TRY(sf_exec_prepare(ex));
+    static const bool no_lookahead = getenv("SF_NO_LOOKAHEAD") != nullptr;
+    hipStream_t c = no_lookahead ? s : ex->side;
+    hipEvent_t e_fork;
+    SF_TRY(sf_exec_event(ex, &e_fork));
+    SF_HIP(hipEventRecord(e_fork, s));
+    SF_HIP(hipStreamWaitEvent(c, e_fork, 0));
+
+    auto launch_panel = [&](int k0, int pw, int row0, int nslab, const double* Wt, bool to_scratch,
+                            hipStream_t st) -> int {
+        sf_panel_args g = {};
+        g.C = A;
+        g.sC = stride;
+        g.lda = lda;
+        g.n = n;
+        g.k0 = k0;
+        g.pw = pw;
+        g.row0 = row0;
+        g.nslab = nslab;
+        g.Wt = Wt;
+        g.sW = sW;
+        g.rhs = rhs;
+        g.ldr = ldr;
+        if (to_scratch) {
+            g.Sout = T;
+            g.sS = sT;
+            g.ldS = SF_LDT;
+        }
+        if (gen) {
+            g.genY = gen->Y;
+            g.sY = (int64_t)gen->mpad * gen->ldy;
+            g.ldy = gen->ldy;
+            g.mpad = gen->mpad;
+            g.tilemap = gen->tilemap;
+            g.nt128 = gen->nt128;
+        }
+        const long long nblk = (long long)nslab * batch;
+        if (nblk > 0x7fffffffLL) {
+            sf_set_error("panel grid too large");
+            return SF_EINVAL;
+        }
+        // algorithmic flops: update 2 k0 rows pw, solve rows pw^2, symmetric rank-pw update of the lower tiles
+        const double rows = (double)((n - row0 < nslab * GT) ? n - row0 : nslab * GT);
+        const double flops = (2.0 * k0 * rows * pw + rows * pw * (double)pw + (double)GT * rows * pw) * batch;
+        void* tok;
+        sf_prof_gemm_begin(st, flops, &tok);
+        if (rhs)
+            hipLaunchKernelGGL(k_chol_panel<true>, dim3((unsigned)nblk), dim3(512), 0, st, g);
+        else
+            hipLaunchKernelGGL(k_chol_panel<false>, dim3((unsigned)nblk), dim3(512), 0, st, g);
+        sf_prof_gemm_end(tok);
+        SF_LAUNCH_CHECK();
+        return SF_OK;
+    };
+
+    // diagonal tile 0 goes to the scratch unchanged
+    SF_TRY(launch_panel(0, 0, 0, 1, nullptr, true, c));
+    hipEvent_t e_rest_prev = nullptr;
+    int panel = 0;
+    for (int k0 = 0; k0 < n; k0 += GT, ++panel) {
+        const int pw = (n - k0 < GT) ? n - k0 : GT;
+        const int k1 = k0 + pw;
+        double* Wt = Wt2 + (size_t)(panel & 1) * batch * sW;
+        hipLaunchKernelGGL(k_diag_mfma<512>, dim3(batch), dim3(512), 0, c, T, sT, pw, info, k0,
+                           rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
+        SF_LAUNCH_CHECK();
+        if (k1 >= n) break;
+        hipEvent_t e_d;
+        SF_TRY(sf_exec_event(ex, &e_d));
+        SF_HIP(hipEventRecord(e_d, c));
+        // top(k): the slab of the next diagonal tile, on the chain
+        if (e_rest_prev) SF_HIP(hipStreamWaitEvent(c, e_rest_prev, 0));
+        SF_TRY(launch_panel(k0, pw, k1, 1, Wt, true, c));
+        // rest(k): everything below, on the caller's stream
+        const int rbelow = n - (k1 + GT);
+        if (rbelow > 0) {
+            SF_HIP(hipStreamWaitEvent(s, e_d, 0));
+            SF_TRY(launch_panel(k0, pw, k1 + GT, (rbelow + GT - 1) / GT, Wt, false, s));
+            SF_TRY(sf_exec_event(ex, &e_rest_prev));
+            SF_HIP(hipEventRecord(e_rest_prev, s));
+        }
+    }
+    hipEvent_t e_join;
+    SF_TRY(sf_exec_event(ex, &e_join));
+    SF_HIP(hipEventRecord(e_join, c));
+    SF_HIP(hipStreamWaitEvent(s, e_join, 0));
+    return SF_OK;
+}
+
+int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
+                    double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
+    static const bool v1 = getenv("SF_CHOL_UNFUSED") != nullptr;  // tuning aid: the round-1 launch sequence
+    if (!ex) ex = sf_exec_thread_local();
+    return v1 ? sf_launch_potrf_v1(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex)
+              : sf_launch_potrf_v2(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
 }
 
 int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int batch, const double* R,

@@ -44,6 +44,22 @@ static inline bool sf_first_use_on_device(unsigned long long* seen) {
     return true;
 }
 
+// Streams and events a launch sequence needs besides the caller's stream.  Owned by a context (sf_ctx) or,
+// for the context-free entry points, by the calling thread -- the library keeps no process-global stream state,
+// so contexts can be driven from different host threads (and devices) concurrently.
+struct sf_exec {
+    int device = -1;
+    hipStream_t side = nullptr;  // highest priority: the diagonal-block chain of the Cholesky
+    hipStream_t aux = nullptr;   // banded path: band fill beside the transforms
+    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t* pool = nullptr;
+    size_t pool_size = 0, pool_cap = 0, used = 0;
+};
+int sf_exec_prepare(sf_exec* ex);               // streams of the CURRENT device (created on first use), pool rewound
+int sf_exec_event(sf_exec* ex, hipEvent_t* e);  // next pooled event (timing disabled)
+void sf_exec_release(sf_exec* ex);
+sf_exec* sf_exec_thread_local(void);
+
 // profiling hooks (sf_abi.cpp)
 void sf_prof_gemm_begin(hipStream_t s, double flops, void** tok);
 void sf_prof_gemm_end(void* tok);
@@ -62,7 +78,7 @@ struct sf_gen_args {
     int nt128;
 };
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
-                    double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen = nullptr);
+                    double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen = nullptr, sf_exec* ex = nullptr);
 int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batch, const double* z, int ldr,
                        double* logdet, double* sqmah, hipStream_t s);
 int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int batch,

@@ -1,9 +1,10 @@
 # Per-launch timeline of one sf_potrf_batch call (tuning aid):  bash tools/trace_potrf.sh [ENV=VAL ...]
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
+NN=${NN:-4096}; BB=${BB:-128}
 for kv in "$@"; do export "$kv"; done
 rm -rf $R/gpurun_out/trace_potrf
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_potrf -- python $R/tools/bench_potrf.py 4096 128 1 > $R/gpurun_out/trace_potrf.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_potrf -- python $R/tools/bench_potrf.py $NN $BB 1 > $R/gpurun_out/trace_potrf.log 2>&1
 grep "potrf " $R/gpurun_out/trace_potrf.log
 python - <<'PY'
 import csv, glob, os
