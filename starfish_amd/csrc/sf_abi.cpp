@@ -113,6 +113,7 @@ int sf_exec_prepare(sf_exec* ex) {
         SF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         SF_HIP(hipStreamCreateWithPriority(&ex->side, hipStreamNonBlocking, prio_hi));
         SF_HIP(hipStreamCreateWithFlags(&ex->aux, hipStreamNonBlocking));
+        for (int g = 0; g < SF_EXEC_GROUPS - 1; ++g) SF_HIP(hipStreamCreateWithFlags(&ex->grp[g], hipStreamNonBlocking));
         SF_HIP(hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming));
         SF_HIP(hipEventCreateWithFlags(&ex->join, hipEventDisableTiming));
         ex->device = dev;
@@ -149,6 +150,10 @@ void sf_exec_release(sf_exec* ex) {
     if (ex->join) (void)hipEventDestroy(ex->join);
     if (ex->side) (void)hipStreamDestroy(ex->side);
     if (ex->aux) (void)hipStreamDestroy(ex->aux);
+    for (int g = 0; g < SF_EXEC_GROUPS - 1; ++g) {
+        if (ex->grp[g]) (void)hipStreamDestroy(ex->grp[g]);
+        ex->grp[g] = nullptr;
+    }
     ex->fork = ex->join = nullptr;
     ex->side = ex->aux = nullptr;
     ex->device = -1;

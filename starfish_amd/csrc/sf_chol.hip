@@ -921,7 +921,14 @@ struct sf_panel_args {
     int64_t sC;
     int lda, n;
     int k0, pw;       // panel columns [k0, k0 + pw), pw in {0, 64, 128}
-    int row0, nslab;  // slabs of 128 rows starting at row0 (multiple of 128); the last one may be shorter
+    int row0, nslab;  // nslab slabs of 128 rows, the first at row0 (multiple of 128); the last one may be shorter
+    int slab_step;    // distance between consecutive slabs of this launch, in slabs (slab groups are interleaved)
+    int skip;         // tuning aid (wrong results, timing only): 1 no solve, 2 no rank-pw update, 4 no main loop
+    // split-K for launches that cannot fill the chip (late panels, small batches): mode 1 = ksplit workgroups per
+    // slab each accumulate kchunk K-slabs and park their 128 x 128 partial sum in `part`; mode 2 = one workgroup
+    // per slab adds the partial sums in fixed order (deterministic) and runs steps 2-4; mode 0 = everything at once
+    int ksplit, kchunk;
+    double* part;     // [tiles * ksplit][128 * 128]
     const double* Wt; // [batch] x sW: Wt[c][k] = (L_kk^-1)[c][k], row stride SF_LDT
     int64_t sW;
     double* rhs;      // [batch] x ldr or NULL
@@ -935,7 +942,25 @@ struct sf_panel_args {
     int ldy, mpad, nt128;
 };
 
-template <bool RHS>
+// one 16-wide K block of the triangular solve for the 16-column blocks ni >= NI_LO of a wave
+template <int NI_LO>
+__device__ __forceinline__ void sf_solve_step(sf_d4 (&acc)[2][4], const double* Ab, const double* Bb) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        double a[2], bb[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = Ab[i * 16 * CLD + ks * 4];
+#pragma unroll
+        for (int i = NI_LO; i < 4; ++i) bb[i] = Bb[i * 16 * GLD + ks * 4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = NI_LO; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+template <bool RHS, int MODE>
 __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
     constexpr int TM = 2, TN = 4;
     __shared__ __attribute__((aligned(16))) double sm[4 * GT * GLD];
@@ -945,9 +970,11 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
     double* Ach = sm;  // 128 x CLD chunk buffer of the epilogue (aliases As)
 
     const int id = sf_xcd_remap(blockIdx.x, gridDim.x);
-    const int b = id / g.nslab;
-    const int sl = id - b * g.nslab;
-    const int row0 = g.row0 + sl * GT;
+    const int tile = MODE == 1 ? id / g.ksplit : id;
+    const int sp = MODE == 1 ? id - tile * g.ksplit : 0;
+    const int b = tile / g.nslab;
+    const int sl = tile - b * g.nslab;
+    const int row0 = g.row0 + sl * g.slab_step * GT;
     const int rows_here = min(GT, g.n - row0);
     const int pw = g.pw, k0 = g.k0;
 
@@ -988,12 +1015,37 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
                 pb[1] = rb[p].y;
             }
         };
-        const int nk = k0 / GK;
-        if (nk > 0) gload(0);
+        const int nk_all = (g.skip & 4) ? 0 : k0 / GK;
+        const int kbeg = MODE == 1 ? min(sp * g.kchunk, nk_all) : 0;
+        const int kend = MODE == 1 ? min(kbeg + g.kchunk, nk_all) : (MODE == 2 ? 0 : nk_all);
+        const int nk = kend - kbeg;
+        if (nk > 0) gload(kbeg);
 
         bool generate = false;
         if (g.tilemap) generate = !g.tilemap[(int64_t)b * g.nt128 * g.nt128 + (row0 / GT) * g.nt128 + k0 / GT];
-        if (generate) {
+        if (MODE == 2) {
+            // the partial sums of the split-K workgroups, added in split order
+            const double* P = g.part + (int64_t)tile * g.ksplit * (GT * GT);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+            for (int q = 0; q < g.ksplit; ++q) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[mi][ni][r] += P[(int64_t)q * (GT * GT) + (wm * (16 * TM) + mi * 16 + lq + 4 * r) * GT +
+                                                wn * (16 * TN) + ni * 16 + l15];
+            }
+        } else if (MODE == 1 && sp > 0) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+        } else if (generate) {
             const double* Yb = g.genY + (int64_t)b * g.sY;
             const int gr = row0 + wm * (16 * TM) + l15;
             const int gc = k0 + wn * (16 * TN) + l15;
@@ -1050,15 +1102,26 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             }
         };
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            gload(kt + 1);
+            gload(kbeg + kt + 1);
             compute(kt & 1);
             lstore((kt & 1) ^ 1);
             __syncthreads();
         }
         if (nk > 0) compute((nk - 1) & 1);
+        if (MODE == 1) {
+            double* P = g.part + ((int64_t)tile * g.ksplit + sp) * (GT * GT);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        P[(wm * (16 * TM) + mi * 16 + lq + 4 * r) * GT + wn * (16 * TN) + ni * 16 + l15] = acc[mi][ni][r];
+            return;
+        }
 
         // ---------------------------------------------------------------- 2: L = T W through LDS
-        const int nsb = pw >> 4;  // 16-column blocks of the panel (4 or 8)
+        const int nsb = (g.skip & 1) ? 0 : pw >> 4;  // 16-column blocks of the panel (4 or 8)
         const double* Wp[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p)
@@ -1093,7 +1156,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
                     }
                 }
         };
-        wload(nsb - 1);
+        if (nsb > 0) wload(nsb - 1);
         int buf = 0;
         // (fully unrolled: chunk and block indices are compile-time constants, only wave-uniform branches remain)
 #pragma unroll
@@ -1109,23 +1172,12 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             if (sb > 0) wload(sb - 1);
             // W[k][c] = 0 for k > c: this wave's 64 columns need the blocks k <= 4 wn + 3 only (one wave-uniform
             // branch around a straight-line body; inside it the zero blocks of W are multiplied through, which
-            // leaves the not-yet-dumped T blocks and the finished sums bit-for-bit unchanged)
+            // leaves the not-yet-dumped T blocks and the finished sums bit-for-bit unchanged.  Skipping block by
+            // block -- a switch over four straight-line bodies -- makes hipcc spill ~250 VGPRs: measured, not kept)
             if (sb <= wn * TN + (TN - 1)) {
                 const double* Ab = &Ach[(wm * (16 * TM) + l15) * CLD + (sb & 1) * 16 + lq];
                 const double* Bb = &Bs[buf][(wn * (16 * TN) + l15) * GLD + lq];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    double a[TM], bb[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = Ab[i * 16 * CLD + ks * 4];
-#pragma unroll
-                    for (int i = 0; i < TN; ++i) bb[i] = Bb[i * 16 * GLD + ks * 4];
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < TN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
-                }
+                sf_solve_step<0>(acc, Ab, Bb);
             }
             buf ^= 1;
         }
@@ -1172,7 +1224,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
     // wave: the L accumulators stay live while their chunks are dumped, 5 more blocks do not fit the budget
     {
         const int p = w >> 1, h = w & 1;
-        const int nch = pw >> 5;
+        const int nch = (g.skip & 2) ? 0 : pw >> 5;
         const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
         double* So = g.Sout ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
         const int ldo = g.Sout ? g.ldS : g.lda;
@@ -1254,9 +1306,27 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
 // 32 KiB every workgroup of the batch touches the same HBM channel / L2 bank at the same time (measured:
 // 3.6 us per dependent load in k_diag_mfma before the skew).
 #define SF_TSKEW 40
+// Split-K policy of the fused factorisation: a launch of `wgs` workgroups with `nk` K-slabs each is split
+// `S` ways when it cannot fill the chip (512 resident workgroups): late panels and small batches, where the
+// time of a launch is the time of ONE workgroup's K loop.  S is a power of two, every part keeps >= 8 slabs.
+#define SF_CHIP_WGS 512
+#define SF_SPLIT_MAX 8
+static int sf_split_policy(long long wgs, int nk) {
+    static const int force = getenv("SF_CHOL_SPLIT") ? atoi(getenv("SF_CHOL_SPLIT")) : -1;  // tuning aid
+    int S = 1;
+    while (2 * S <= SF_SPLIT_MAX && wgs * 2 * S <= SF_CHIP_WGS && nk / (2 * S) >= 8) S *= 2;
+    if (force >= 1) {
+        S = 1;
+        while (2 * S <= force && 2 * S <= SF_SPLIT_MAX && wgs * 2 * S <= 2 * SF_CHIP_WGS && nk / (2 * S) >= 8) S *= 2;
+    }
+    return S;
+}
+// partial-sum tiles: one region for the chain (top) launches, one per slab group
+static size_t sf_split_region_tiles(void) { return 2 * SF_CHIP_WGS; }
 size_t sf_potrf_work_doubles(int n, int batch) {
     const size_t b = (size_t)batch;
-    return b * SF_LTB_DOUBLES + b * ((size_t)(n + SF_NB) * SF_LDT + SF_TSKEW) + 2 * b * ((size_t)SF_NB * SF_LDT + SF_TSKEW) + 64;
+    return b * SF_LTB_DOUBLES + b * ((size_t)(n + SF_NB) * SF_LDT + SF_TSKEW) + 2 * b * ((size_t)SF_NB * SF_LDT + SF_TSKEW) + 64 +
+           (size_t)(SF_EXEC_GROUPS + 1) * sf_split_region_tiles() * (GT * GT);
 }
 
 // ---- two-stream lookahead ---------------------------------------------------------------------
@@ -1471,10 +1541,12 @@ static int sf_launch_potrf_v1(double* A, int n, int lda, int64_t stride, int bat
 // Factorisation with the fused panel kernel (default).  Panels of 128 columns; per panel k
 //   D(k)      k_diag_mfma on the updated diagonal tile (parked in the scratch T): L_kk, L_kk^-1, z_k
 //   top(k)    k_chol_panel for the slab of the NEXT diagonal tile (rows k1 .. k1+128): its updated tile goes to T
-//   rest(k)   k_chol_panel for all slabs below
-// Lookahead on two streams: side  D(k) -> [wait rest(k-1)] top(k) -> D(k+1) ...
-//                           main  [wait D(k)] rest(k) ...
-// rest(k) only needs D(k), which ran beside rest(k-1); top(k) needs the rows rest(k-1) finished.
+//   rest(k)   k_chol_panel for all slabs below, as G launches on G streams: slab i belongs to group i mod G
+// Lookahead: the chain  D(k) -> [wait group of slab k+1] top(k) -> D(k+1) ...  runs on the side stream;
+// group g only needs D(k) (which ran beside rest(k-1)) and its own previous launch (a slab stays in its
+// group), so there is no chip-wide barrier between panels: while one group's launch drains its last
+// workgroups the other groups keep the CUs full (one launch per panel left 0.25-0.75 of a round of 512
+// workgroups idle at every panel boundary).
 static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
                               double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
     if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
@@ -1488,14 +1560,21 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
     SF_TRY(sf_exec_prepare(ex));
     static const bool no_lookahead = getenv("SF_NO_LOOKAHEAD") != nullptr;
+    static const int ngroups_env = getenv("SF_CHOL_GROUPS") ? atoi(getenv("SF_CHOL_GROUPS")) : SF_EXEC_GROUPS;
+    const int G = no_lookahead ? 1 : (ngroups_env < 1 ? 1 : (ngroups_env > SF_EXEC_GROUPS ? SF_EXEC_GROUPS : ngroups_env));
     hipStream_t c = no_lookahead ? s : ex->side;
+    hipStream_t gs[SF_EXEC_GROUPS];
+    for (int g = 0; g < G; ++g) gs[g] = g == 0 ? s : ex->grp[g - 1];
     hipEvent_t e_fork;
     SF_TRY(sf_exec_event(ex, &e_fork));
     SF_HIP(hipEventRecord(e_fork, s));
-    SF_HIP(hipStreamWaitEvent(c, e_fork, 0));
+    if (c != s) SF_HIP(hipStreamWaitEvent(c, e_fork, 0));
+    for (int g = 1; g < G; ++g) SF_HIP(hipStreamWaitEvent(gs[g], e_fork, 0));
 
-    auto launch_panel = [&](int k0, int pw, int row0, int nslab, const double* Wt, bool to_scratch,
-                            hipStream_t st) -> int {
+    double* part = Wt2 + 2 * (size_t)batch * sW + 64;  // split-K partial sums: region 0 = chain, 1 + g = group g
+    const int nt = (n + GT - 1) / GT;
+    auto launch_panel = [&](int k0, int pw, int row0, int nslab, int step, const double* Wt, bool to_scratch,
+                            hipStream_t st, int region) -> int {
         sf_panel_args g = {};
         g.C = A;
         g.sC = stride;
@@ -1505,6 +1584,9 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
         g.pw = pw;
         g.row0 = row0;
         g.nslab = nslab;
+        g.slab_step = step;
+        static const int skip = getenv("SF_PANEL_SKIP") ? atoi(getenv("SF_PANEL_SKIP")) : 0;
+        g.skip = skip;
         g.Wt = Wt;
         g.sW = sW;
         g.rhs = rhs;
@@ -1528,50 +1610,82 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
             return SF_EINVAL;
         }
         // algorithmic flops: update 2 k0 rows pw, solve rows pw^2, symmetric rank-pw update of the lower tiles
-        const double rows = (double)((n - row0 < nslab * GT) ? n - row0 : nslab * GT);
+        double rows = 0.0;
+        for (int i = 0; i < nslab; ++i) {
+            const int r0 = row0 + i * step * GT;
+            rows += (n - r0 < GT) ? n - r0 : GT;
+        }
         const double flops = (2.0 * k0 * rows * pw + rows * pw * (double)pw + (double)GT * rows * pw) * batch;
+        const int nk = k0 / GK;
+        const int S = pw > 0 ? sf_split_policy(nblk, nk) : 1;
         void* tok;
         sf_prof_gemm_begin(st, flops, &tok);
-        if (rhs)
-            hipLaunchKernelGGL(k_chol_panel<true>, dim3((unsigned)nblk), dim3(512), 0, st, g);
-        else
-            hipLaunchKernelGGL(k_chol_panel<false>, dim3((unsigned)nblk), dim3(512), 0, st, g);
+        if (S > 1) {
+            g.ksplit = S;
+            g.kchunk = (nk + S - 1) / S;
+            g.part = part + (size_t)region * sf_split_region_tiles() * (GT * GT);
+            hipLaunchKernelGGL((k_chol_panel<false, 1>), dim3((unsigned)(nblk * S)), dim3(512), 0, st, g);
+            if (rhs)
+                hipLaunchKernelGGL((k_chol_panel<true, 2>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+            else
+                hipLaunchKernelGGL((k_chol_panel<false, 2>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+        } else if (rhs) {
+            hipLaunchKernelGGL((k_chol_panel<true, 0>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+        } else {
+            hipLaunchKernelGGL((k_chol_panel<false, 0>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+        }
         sf_prof_gemm_end(tok);
         SF_LAUNCH_CHECK();
         return SF_OK;
     };
 
     // diagonal tile 0 goes to the scratch unchanged
-    SF_TRY(launch_panel(0, 0, 0, 1, nullptr, true, c));
-    hipEvent_t e_rest_prev = nullptr;
-    int panel = 0;
-    for (int k0 = 0; k0 < n; k0 += GT, ++panel) {
+    SF_TRY(launch_panel(0, 0, 0, 1, 1, nullptr, true, c, 0));
+    hipEvent_t e_rest[SF_EXEC_GROUPS] = {};       // last launch of every group
+    hipEvent_t e_rest_prev[SF_EXEC_GROUPS] = {};  // ... one panel earlier (their readers of Wt[panel & 1])
+    for (int k = 0; k < nt; ++k) {
+        const int k0 = k * GT;
         const int pw = (n - k0 < GT) ? n - k0 : GT;
-        const int k1 = k0 + pw;
-        double* Wt = Wt2 + (size_t)(panel & 1) * batch * sW;
+        double* Wt = Wt2 + (size_t)(k & 1) * batch * sW;
+        // D(k) overwrites the W buffer of panel k-2: every group must be done reading it
+        if (c != s || G > 1)
+            for (int g = 0; g < G; ++g)
+                if (e_rest_prev[g] && (c != gs[g])) SF_HIP(hipStreamWaitEvent(c, e_rest_prev[g], 0));
         hipLaunchKernelGGL(k_diag_mfma<512>, dim3(batch), dim3(512), 0, c, T, sT, pw, info, k0,
                            rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
         SF_LAUNCH_CHECK();
-        if (k1 >= n) break;
+        if (k + 1 >= nt) break;
         hipEvent_t e_d;
         SF_TRY(sf_exec_event(ex, &e_d));
         SF_HIP(hipEventRecord(e_d, c));
-        // top(k): the slab of the next diagonal tile, on the chain
-        if (e_rest_prev) SF_HIP(hipStreamWaitEvent(c, e_rest_prev, 0));
-        SF_TRY(launch_panel(k0, pw, k1, 1, Wt, true, c));
-        // rest(k): everything below, on the caller's stream
-        const int rbelow = n - (k1 + GT);
-        if (rbelow > 0) {
-            SF_HIP(hipStreamWaitEvent(s, e_d, 0));
-            SF_TRY(launch_panel(k0, pw, k1 + GT, (rbelow + GT - 1) / GT, Wt, false, s));
-            SF_TRY(sf_exec_event(ex, &e_rest_prev));
-            SF_HIP(hipEventRecord(e_rest_prev, s));
+        // top(k): the slab of the next diagonal tile, on the chain; its row was finished by the group of slab k+1
+        {
+            hipEvent_t dep = e_rest[(k + 1) % G];
+            if (dep && c != gs[(k + 1) % G]) SF_HIP(hipStreamWaitEvent(c, dep, 0));
+        }
+        SF_TRY(launch_panel(k0, pw, (k + 1) * GT, 1, 1, Wt, true, c, 0));
+        // rest(k): slabs k+2 .. nt-1, slab i on the stream of group i mod G
+        for (int g = 0; g < G; ++g) e_rest_prev[g] = e_rest[g];
+        for (int g = 0; g < G; ++g) {
+            int first = k + 2;
+            while (first % G != g) ++first;
+            if (first >= nt) continue;
+            const int cnt = (nt - 1 - first) / G + 1;
+            if (gs[g] != c) SF_HIP(hipStreamWaitEvent(gs[g], e_d, 0));
+            SF_TRY(launch_panel(k0, pw, first * GT, cnt, G, Wt, false, gs[g], 1 + g));
+            SF_TRY(sf_exec_event(ex, &e_rest[g]));
+            SF_HIP(hipEventRecord(e_rest[g], gs[g]));
         }
     }
+    // join: the caller's stream continues only after the chain and every group are done
     hipEvent_t e_join;
-    SF_TRY(sf_exec_event(ex, &e_join));
-    SF_HIP(hipEventRecord(e_join, c));
-    SF_HIP(hipStreamWaitEvent(s, e_join, 0));
+    if (c != s) {
+        SF_TRY(sf_exec_event(ex, &e_join));
+        SF_HIP(hipEventRecord(e_join, c));
+        SF_HIP(hipStreamWaitEvent(s, e_join, 0));
+    }
+    for (int g = 1; g < G; ++g)
+        if (e_rest[g]) SF_HIP(hipStreamWaitEvent(s, e_rest[g], 0));
     return SF_OK;
 }
 

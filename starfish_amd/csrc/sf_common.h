@@ -47,9 +47,11 @@ static inline bool sf_first_use_on_device(unsigned long long* seen) {
 // Streams and events a launch sequence needs besides the caller's stream.  Owned by a context (sf_ctx) or,
 // for the context-free entry points, by the calling thread -- the library keeps no process-global stream state,
 // so contexts can be driven from different host threads (and devices) concurrently.
+#define SF_EXEC_GROUPS 2  // streams the slab groups of the fused Cholesky are spread over (the caller's + 1; measured: 1 -> 54.8, 2 -> 52.9, 3 -> 53.8 ms at cfg 2)
 struct sf_exec {
     int device = -1;
     hipStream_t side = nullptr;  // highest priority: the diagonal-block chain of the Cholesky
+    hipStream_t grp[SF_EXEC_GROUPS - 1] = {};  // slab groups 1.. of the fused Cholesky (group 0 = caller's stream)
     hipStream_t aux = nullptr;   // banded path: band fill beside the transforms
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t* pool = nullptr;

@@ -12,7 +12,7 @@ R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 f = glob.glob(R + "/gpurun_out/trace_potrf/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # last potrf call = launches after the last elementwise copy kernel preceding the final k_gemm_nt burst
-idx = [i for i, r in enumerate(rows) if "k_gemm_nt" in r["Kernel_Name"] or "k_diag_mfma" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("k_gemm_nt", "k_diag_mfma", "k_chol_panel"))]
 # split bursts by gaps > 2 ms
 bursts, cur = [], [idx[0]]
 for a, b in zip(idx, idx[1:]):
