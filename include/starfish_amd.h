@@ -21,14 +21,19 @@
  *     <0 = SF_INFO_* (parameter outside the emulator grid, non-positive vsini, ...).
  *   - all matrices are row-major; the Cholesky factor is the LOWER triangle (A = L L^T), the strict
  *     upper triangle is not referenced.
- *   - the batched Cholesky forks part of its launches onto a library-owned side stream (lookahead) and
- *     joins it back to `stream` with an event before returning: from the caller's point of view all
- *     work is ordered on `stream`.  The library keeps process-global state (side stream, event pool,
- *     timing hooks): issue calls from ONE host thread per process (one process per GPU).
+ *   - the batched Cholesky forks part of its launches onto side streams (lookahead, slab groups) and
+ *     joins them back to `stream` with events before returning: from the caller's point of view all
+ *     work is ordered on `stream`.  Those streams and their event pool belong to the CONTEXT (to the
+ *     calling thread for the context-free entry points): different contexts may be driven from
+ *     different host threads, and live on different devices, concurrently; ONE context is not
+ *     re-entrant (like the reference's model object).  Every context call makes the context's device
+ *     current for the calling thread.  Only the bench timing hooks (sf_profile_*) are process-global
+ *     (mutex-protected).
  *   - environment switches (tuning aids, read once): SF_NO_LOOKAHEAD=1 single-stream Cholesky,
- *     SF_LEAF_DIAG=1 diagonal-block step as a chain of register-level leaf kernels instead of the
- *     one-launch MFMA kernel, SF_GEMM_256=1 / SF_GEMM_1024=1 alternative wave layouts of the MFMA
- *     update kernel (default: 512 threads, measured fastest), SF_BAND_NO_TWIST=1 single-sweep banded solver.
+ *     SF_CHOL_UNFUSED=1 the round-1 launch sequence (256-column panels, separate panel-solve and
+ *     diagonal-update launches) instead of the fused panel kernel, SF_CHOL_GROUPS=1|2 slab groups,
+ *     SF_CHOL_SPLIT=n split-K cap, SF_BAND_NO_TWIST=1 single-sweep banded solver; with SF_CHOL_UNFUSED:
+ *     SF_LEAF_DIAG=1, SF_GEMM_256=1 / SF_GEMM_1024=1 (see sf_chol.hip).
  */
 #ifndef STARFISH_AMD_H
 #define STARFISH_AMD_H
@@ -224,6 +229,28 @@ int sf_loglike_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const doubl
                      double* d_lnl, double* d_logdet, double* d_sqmah, double* d_resid,
                      double* d_log_scale, int* d_info, void* d_work, size_t work_bytes,
                      void* stream);
+
+/* ---- multi-order batches (reference: the multi-order container
+ * Starfish/spectrum.py:96-115, orders independent docs/intro.rst:71-73, EchelleModel stub
+ * Starfish/models/echelle_model.py:1-2) -------------------------------------------------------------
+ * Evaluates the (order x walker) units of several orders in ONE enqueue: segment i is an order
+ * context with its own B_i parameter rows; every order runs its transform chain and covariance fill
+ * into its slice of a common covariance array (orders shorter than the longest one of the group are
+ * padded with an identity block, which changes neither logdet nor the quadratic form) and all
+ * sum(B_i) matrices share one batched Cholesky.  Outputs are concatenated in segment order
+ * (unit = sum_{j<i} B_j + b); the caller sums over orders.  All contexts must live on the same
+ * device and agree in the number of eigenspectra and grid dimensions; one model descriptor describes
+ * the parameter rows of every segment.  Same values as nseg calls of sf_loglike_batch. */
+typedef struct sf_segment {
+    sf_ctx* ctx;
+    const double* d_params; /* DEVICE: B x sf_param_stride() rows of this order */
+    int32_t B;
+    int32_t reserved;
+} sf_segment;
+size_t sf_multi_workspace_bytes(const sf_segment* segs, int nseg, const sf_model_desc* model);
+int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf_model_desc* model,
+                           double* d_lnl, double* d_logdet, double* d_sqmah, double* d_log_scale,
+                           int* d_info, void* d_work, size_t work_bytes, void* stream);
 
 /* ---- structure-exploiting solver -----------------------------------
  * Same value as sf_loglike_batch, computed without ever forming the N x N matrix: the covariance of

@@ -87,6 +87,85 @@ def band_halfwidth_bound(wave, rows, n_grid, has_global, n_local, n_cheb):
     return np.minimum(hw, big).astype(np.int64)
 
 
+def loglike_multi(orders, md, rows_list, max_units=None, sync=True):
+    """(order x walker) units of several orders of ONE device in one enqueue and one host synchronisation
+    (sf_loglike_multi_batch): ``orders`` are :class:`DeviceOrder` objects, ``rows_list[i]`` the (B_i, stride)
+    C-ABI parameter rows of order i.  Returns a list of dicts (lnl, logdet, sqmah, log_scale, info) per order.
+    Batches that do not fit the free HBM (or ``max_units``) are evaluated in chunks of whole-order slices.
+    With ``sync=False`` the device tensors are returned un-synchronised as (quad, info, sizes) for callers
+    that overlap several devices (:func:`collect_multi` finishes the job)."""
+    torch = _torch()
+    lib = orders[0].lib
+    dev = orders[0].dev
+    if any(o.dev != dev for o in orders):
+        raise ValueError("loglike_multi: all orders must live on the same device")
+    sizes = [int(np.atleast_2d(r).shape[0]) for r in rows_list]
+    U = sum(sizes)
+    with torch.cuda.device(dev):
+        P = [r if torch.is_tensor(r) else to_dev(np.atleast_2d(r), dev) for r in rows_list]
+        quad = empty((4, U), dev)
+        info = empty((U,), dev, torch.int32)
+        s = stream_ptr(dev)
+        # chunk plan: consecutive (order, row range) pieces whose workspace fits
+        one = _lib.Segment(orders[0].ctx, ptr(P[0]).value, 1, 0)
+        per_unit = lib.sf_multi_workspace_bytes(C.byref(one), 1, C.byref(md))
+        free, _total = torch.cuda.mem_get_info(dev)
+        ws_old = orders[0]._ws_multi
+        if ws_old is not None:
+            free += ws_old.numel()
+        cap = max(1, int(free * 0.85) // max(per_unit, 1))
+        if max_units:
+            cap = min(cap, int(max_units))
+        pieces, cur, cur_n = [], [], 0
+        for i, n in enumerate(sizes):
+            lo = 0
+            while lo < n:
+                take = min(n - lo, cap - cur_n)
+                cur.append((i, lo, lo + take))
+                cur_n += take
+                lo += take
+                if cur_n == cap:
+                    pieces.append(cur)
+                    cur, cur_n = [], 0
+        if cur:
+            pieces.append(cur)
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        for piece in pieces:
+            segs = (_lib.Segment * len(piece))()
+            for k, (i, lo, hi) in enumerate(piece):
+                segs[k] = _lib.Segment(orders[i].ctx, ptr(P[i][lo:hi]).value, hi - lo, 0)
+            need = lib.sf_multi_workspace_bytes(segs, len(piece), C.byref(md))
+            if need == 0:
+                _lib.check(-1, "sf_multi_workspace_bytes")
+            ws = orders[0]._ws_multi
+            if ws is None or ws.numel() < need:
+                orders[0]._ws_multi = None
+                ws = orders[0]._ws_multi = workspace(need, dev)
+            # the pieces of one call are contiguous in unit order
+            u0 = int(offs[piece[0][0]] + piece[0][1])
+            n_units = sum(hi - lo for _, lo, hi in piece)
+            rc = lib.sf_loglike_multi_batch(
+                segs, len(piece), C.byref(md), ptr(quad[0][u0:u0 + n_units]), ptr(quad[1][u0:u0 + n_units]),
+                ptr(quad[2][u0:u0 + n_units]), ptr(quad[3][u0:u0 + n_units]), ptr(info[u0:u0 + n_units]),
+                ptr(ws), ws.numel(), s,
+            )
+            _lib.check(rc, "sf_loglike_multi_batch")
+        if not sync:
+            return quad, info, sizes
+        return collect_multi(quad, info, sizes)
+
+
+def collect_multi(quad, info, sizes):
+    host = quad.cpu().numpy()
+    hinfo = info.cpu().numpy()
+    out, u = [], 0
+    for n in sizes:
+        out.append(dict(lnl=host[0, u:u + n], logdet=host[1, u:u + n], sqmah=host[2, u:u + n],
+                        log_scale=host[3, u:u + n], info=hinfo[u:u + n]))
+        u += n
+    return out
+
+
 class DeviceOrder:
     """One ``sf_ctx``: the static data of an order + emulator resident in HBM, and the batched calls."""
 
@@ -142,6 +221,7 @@ class DeviceOrder:
         self.npad = self.lib.sf_ctx_npad(self.ctx)
         self.lda = self.lib.sf_ctx_lda(self.ctx)
         self._ws = None
+        self._ws_multi = None  # workspace of loglike_multi calls led by this order
 
     def __del__(self):
         try:
@@ -186,6 +266,7 @@ class DeviceOrder:
 
     def release_workspace(self):
         self._ws = None
+        self._ws_multi = None
 
     # ------------------------------------------------------------------ structure-exploiting solver
     def banded_window_halfwidth(self):
@@ -266,10 +347,7 @@ class DeviceOrder:
         B = rows.shape[0]
         wmax = self.banded_max_halfwidth()
         hw = self.halfwidth_bound(md, rows)
-        fits = hw <= wmax
-        if solver == "banded" and not fits.all():
-            # honour the request for the walkers that fit; the others are reported, not silently densified
-            pass
+        fits = hw <= wmax  # (solver="banded": the walkers that do not fit are reported with info = -4)
         out = dict(
             lnl=np.full(B, -np.inf), logdet=np.full(B, np.nan), sqmah=np.full(B, np.nan),
             log_scale=np.full(B, np.nan), info=np.full(B, INFO_BANDWIDTH, dtype=np.int32),

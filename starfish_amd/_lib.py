@@ -50,6 +50,10 @@ class ModelDesc(C.Structure):
     ]
 
 
+class Segment(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("d_params", C.c_void_p), ("B", C.c_int32), ("reserved", C.c_int32)]
+
+
 # name -> (restype, argtypes); kept in one table so the CPU test-suite can check that every symbol
 # declared in include/starfish_amd.h is exported.
 _VP = C.c_void_p
@@ -113,6 +117,11 @@ SIGNATURES = {
     "sf_loglike_batch": (
         C.c_int,
         [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
+    ),
+    "sf_multi_workspace_bytes": (C.c_size_t, [C.POINTER(Segment), C.c_int, C.POINTER(ModelDesc)]),
+    "sf_loglike_multi_batch": (
+        C.c_int,
+        [C.POINTER(Segment), C.c_int, C.POINTER(ModelDesc), _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
     ),
     "sf_banded_max_halfwidth": (C.c_int, [_VP]),
     "sf_banded_window_halfwidth": (C.c_int, [_VP]),

@@ -617,41 +617,82 @@ struct Carve {
         return r;
     }
 };
+// Row strides / per-unit sizes of the batched buffers.  A single-order call uses the order's own padding; a
+// multi-order call (sf_loglike_multi_batch) pads every order to the largest one of the group so that all
+// units share ONE batched factorisation.
+struct Layout {
+    int m, mpad, M, nf, rows, npad, lda;
+};
+static size_t tilemap_bytes(const Layout& L) {  // per unit: one byte per 128 x 128 tile, as the kernels index it
+    const size_t nt128 = (size_t)(L.npad + 127) / 128;
+    return nt128 * nt128;
+}
+static Layout layout_of(const sf_ctx* c) { return Layout{c->m, c->mpad, c->M, c->nf, c->rows, c->npad, c->lda}; }
 struct Work {
     double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *ybro, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf, *mult, *gtab;
     double2* fft;
     int *info_e, *info_c;
     unsigned char* tilemap;
     size_t bytes;
+    Layout L;
 };
-static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, size_t cap, bool need_C) {
+// B units of per-unit buffers; the transient buffers of the transform chain (used by one launch sequence at a
+// time, stream ordered) are sized for Bt walkers
+static Work carve(const Layout& L, const sf_model_desc* mdl, int B, int Bt, void* p, size_t cap, bool need_C) {
     Carve k(p, cap);
     Work w;
-    const size_t b = (size_t)B;
-    w.mu = k.take<double>(b * c->m);
-    w.Lw = k.take<double>(b * c->m * c->m);
-    w.zs = k.take<double>(b * c->m * c->M * c->m);
+    w.L = L;
+    const size_t b = (size_t)B, bt = (size_t)Bt;
+    w.mu = k.take<double>(b * L.m);
+    w.Lw = k.take<double>(b * L.m * L.m);
+    w.zs = k.take<double>(b * L.m * L.M * L.m);
     w.scale = k.take<double>(b);
     w.logdet = k.take<double>(b);
     w.sqmah = k.take<double>(b);
     w.info_e = k.take<int>(b);
     w.info_c = k.take<int>(b);
-    w.coef = mdl->has_vsini ? k.take<double>(b * c->nf * c->rows) : nullptr;
-    w.ybro = mdl->has_vsini ? k.take<double>(b * c->nf * c->rows) : nullptr;  // broadened rows before the fit
-    w.mult = mdl->has_vsini ? k.take<double>(b * (c->nf / 2 + 1)) : nullptr;  // broadening kernel per walker
-    const size_t fb = mdl->has_vsini ? sf_fft_half_scratch_bytes(B * c->rows, c->nf) : 0;
+    w.coef = mdl->has_vsini ? k.take<double>(bt * L.nf * L.rows) : nullptr;
+    w.ybro = mdl->has_vsini ? k.take<double>(bt * L.nf * L.rows) : nullptr;  // broadened rows before the fit
+    w.mult = mdl->has_vsini ? k.take<double>(bt * (L.nf / 2 + 1)) : nullptr;  // broadening kernel per walker
+    const size_t fb = mdl->has_vsini ? sf_fft_half_scratch_bytes(Bt * L.rows, L.nf) : 0;
     w.fft = fb ? k.take<double2>(fb / sizeof(double2)) : nullptr;
-    w.Xraw = k.take<double>(b * c->m * c->npad);
-    w.fraw = k.take<double>(b * c->npad);
-    w.resid = k.take<double>(b * c->npad);
-    w.Y = k.take<double>(b * c->mpad * c->npad);
-    w.ztrsv = k.take<double>(b * c->npad);
-    w.ltbuf = need_C ? k.take<double>(sf_potrf_work_doubles(c->npad, B)) : nullptr;  // Cholesky scratch
-    w.tilemap = need_C ? k.take<unsigned char>(b * (size_t)(c->npad / 128 + 1) * (c->npad / 128 + 1)) : nullptr;
-    w.gtab = need_C ? k.take<double>(b * (size_t)c->npad) : nullptr;
-    w.C = need_C ? k.take<double>(b * (size_t)c->npad * c->lda) : nullptr;
+    w.Xraw = k.take<double>(b * L.m * L.npad);
+    w.fraw = k.take<double>(b * L.npad);
+    w.resid = k.take<double>(b * L.npad);
+    w.Y = k.take<double>(b * L.mpad * L.npad);
+    w.ztrsv = k.take<double>(b * L.npad);
+    w.ltbuf = need_C ? k.take<double>(sf_potrf_work_doubles(L.npad, B)) : nullptr;  // Cholesky scratch
+    w.tilemap = need_C ? k.take<unsigned char>(b * tilemap_bytes(L)) : nullptr;
+    w.gtab = need_C ? k.take<double>(b * (size_t)L.npad) : nullptr;
+    w.C = need_C ? k.take<double>(b * (size_t)L.npad * L.lda) : nullptr;
     w.bytes = sf_align_up(k.off, 256);
     return w;
+}
+static Work carve(const sf_ctx* c, const sf_model_desc* mdl, int B, void* p, size_t cap, bool need_C) {
+    return carve(layout_of(c), mdl, B, B, p, cap, need_C);
+}
+// the buffers of the units [u0, ...) of a multi-order workspace (transient buffers are shared)
+static Work slice(const Work& w, int u0) {
+    Work s = w;
+    const Layout& L = w.L;
+    const size_t u = (size_t)u0;
+    s.mu += u * L.m;
+    s.Lw += u * L.m * L.m;
+    s.zs += u * L.m * L.M * L.m;
+    s.scale += u;
+    s.logdet += u;
+    s.sqmah += u;
+    s.info_e += u;
+    s.info_c += u;
+    s.Xraw += u * L.m * L.npad;
+    s.fraw += u * L.npad;
+    s.resid += u * L.npad;
+    s.Y += u * L.mpad * L.npad;
+    s.ztrsv += u * L.npad;
+    if (s.tilemap) s.tilemap += u * tilemap_bytes(L);
+    if (s.gtab) s.gtab += u * (size_t)L.npad;
+    if (s.C) s.C += u * (size_t)L.npad * L.lda;
+    return s;
 }
 extern "C" size_t sf_workspace_bytes(const sf_ctx* c, const sf_model_desc* mdl, int B) {
     if (model_ok(c, mdl) || B <= 0) return 0;
@@ -739,7 +780,7 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
     ev.n = c->n;
     ev.nf = c->nf;
     ev.m = c->m;
-    ev.ldx = c->npad;
+    ev.ldx = w.L.npad;
     ev.pstride = pstride;
     ev.has_vz = mdl->has_vz;
     ev.n_cheb = mdl->n_cheb;
@@ -758,7 +799,7 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
     sc.scale = w.scale;
     sc.log_scale_out = d_log_scale;
     sc.n = c->n;
-    sc.ldx = c->npad;
+    sc.ldx = w.L.npad;
     sc.pstride = pstride;
     sc.has_log_scale = mdl->has_log_scale;
     rc = sf_launch_scale(sc, B, s);
@@ -778,13 +819,13 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
     r.n = c->n;
     r.m = c->m;
     r.mpad = c->mpad;
-    r.ldx = c->npad;
-    r.ldy = c->npad;
+    r.ldx = w.L.npad;
+    r.ldy = w.L.npad;
     r.use_sigma_w = mdl->use_sigma_w;
     rc = sf_launch_resid_y(r, B, s);
     if (rc) return rc;
     if (d_resid_out)
-        SF_HIP(hipMemcpy2DAsync(d_resid_out, sizeof(double) * c->n, w.resid, sizeof(double) * c->npad,
+        SF_HIP(hipMemcpy2DAsync(d_resid_out, sizeof(double) * c->n, w.resid, sizeof(double) * w.L.npad,
                                 sizeof(double) * c->n, B, hipMemcpyDeviceToDevice, s));
     return SF_OK;
 }
@@ -796,9 +837,9 @@ static sf_fill_args fill_args(sf_ctx* c, const sf_model_desc* mdl, const double*
     f.Y = w.Y;
     f.params = d_params;
     f.n = c->n;
-    f.npad = c->npad;
+    f.npad = w.L.npad;
     f.mpad = c->mpad;
-    f.ldy = c->npad;
+    f.ldy = w.L.npad;
     f.pstride = sf_param_stride(c, mdl);
     f.has_global = mdl->has_global;
     f.n_local = mdl->n_local;
@@ -949,6 +990,126 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
     }
     if (d_logdet) SF_HIP(hipMemcpyAsync(d_logdet, w.logdet, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, s));
     if (d_sqmah) SF_HIP(hipMemcpyAsync(d_sqmah, w.sqmah, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return SF_OK;
+}
+
+// ------------------------------------------------------------------- multi-order batches
+// The units of several orders (the reference's multi-order spectra, Starfish/spectrum.py:96-115; orders are
+// independent, docs/intro.rst:71-73) share ONE batched factorisation: every order runs its own transform chain
+// and covariance fill into its slice of a common [units][npad][lda] array, padded (identity block) to the largest
+// order of the group; the Cholesky, which is where the time goes, then sees sum(B_i) matrices in one launch
+// sequence instead of nseg half-filled ones, and the host synchronises once.
+static int multi_layout(const sf_segment* segs, int nseg, const sf_model_desc* mdl, Layout* L, int* units, int* bmax) {
+    if (!segs || nseg <= 0 || !mdl) {
+        sf_set_error("multi-order call: bad segment list / model descriptor");
+        return SF_EINVAL;
+    }
+    const sf_ctx* c0 = segs[0].ctx;
+    if (model_ok(c0, mdl)) return SF_EINVAL;
+    *L = layout_of(c0);
+    long long U = 0;
+    int bm = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const sf_ctx* c = segs[i].ctx;
+        if (!c || !c->n || segs[i].B <= 0 || !segs[i].d_params) {
+            sf_set_error("multi-order call: segment %d has no order context / batch / parameters", i);
+            return SF_EINVAL;
+        }
+        if (c->device != c0->device || c->m != c0->m || c->P != c0->P) {
+            sf_set_error("multi-order call: segment %d differs from segment 0 in device, eigenspectra or grid dimensions", i);
+            return SF_EINVAL;
+        }
+        L->M = std::max(L->M, c->M);
+        L->nf = std::max(L->nf, c->nf);
+        L->npad = std::max(L->npad, c->npad);
+        U += segs[i].B;
+        bm = std::max(bm, (int)segs[i].B);
+    }
+    L->lda = L->npad + 16;
+    if (U > 0x3fffffffLL) {
+        sf_set_error("multi-order call: too many units");
+        return SF_EINVAL;
+    }
+    *units = (int)U;
+    *bmax = bm;
+    return SF_OK;
+}
+extern "C" size_t sf_multi_workspace_bytes(const sf_segment* segs, int nseg, const sf_model_desc* mdl) {
+    Layout L;
+    int U = 0, bmax = 0;
+    if (multi_layout(segs, nseg, mdl, &L, &U, &bmax)) return 0;
+    return carve(L, mdl, U, bmax, nullptr, 0, true).bytes;
+}
+extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf_model_desc* mdl, double* d_lnl,
+                                      double* d_logdet, double* d_sqmah, double* d_log_scale, int* d_info,
+                                      void* d_work, size_t work_bytes, void* stream) {
+    Layout L;
+    int U = 0, bmax = 0;
+    int rc = multi_layout(segs, nseg, mdl, &L, &U, &bmax);
+    if (rc) return rc;
+    if (!d_lnl || !d_work) {
+        sf_set_error("sf_loglike_multi_batch: d_lnl and a workspace are required");
+        return SF_EINVAL;
+    }
+    const size_t need = carve(L, mdl, U, bmax, nullptr, 0, true).bytes;
+    if (work_bytes < need) {
+        sf_set_error("workspace too small: have %zu, need %zu", work_bytes, need);
+        return SF_ENOMEM;
+    }
+    sf_ctx* c0 = segs[0].ctx;
+    if (use_device(c0)) return SF_EHIP;
+    hipStream_t s = (hipStream_t)stream;
+    Work W = carve(L, mdl, U, bmax, d_work, work_bytes, true);
+    prof_count_call();
+    const int64_t stride = (int64_t)L.npad * L.lda;
+    const int nt128 = (L.npad + 127) / 128;
+    int u0 = 0;
+    for (int i = 0; i < nseg; ++i) {
+        sf_ctx* c = segs[i].ctx;
+        const int B = segs[i].B;
+        Work w = slice(W, u0);
+        {
+            ProfScope ps(s, PS_TRANSFORM);
+            rc = run_transforms(c, mdl, B, segs[i].d_params, w, nullptr, nullptr, nullptr,
+                                d_log_scale ? d_log_scale + u0 : nullptr, true, s);
+            if (rc) return rc;
+        }
+        {
+            ProfScope ps(s, PS_FILL);
+            sf_fill_args f = fill_args(c, mdl, segs[i].d_params, w);
+            f.C = w.C;
+            f.lda = L.lda;
+            f.stride = stride;
+            f.lower_only = 1;
+            f.add_jitter = 1;
+            f.gtab = w.gtab;
+            f.tilemap = w.tilemap;
+            f.nt128 = nt128;
+            rc = sf_launch_fill(f, B, s);
+            if (rc) return rc;
+        }
+        u0 += B;
+    }
+    {
+        ProfScope ps(s, PS_POTRF);
+        sf_gen_args gen;
+        gen.Y = W.Y;
+        gen.mpad = L.mpad;
+        gen.ldy = L.npad;
+        gen.tilemap = W.tilemap;
+        gen.nt128 = nt128;
+        rc = sf_launch_potrf(W.C, L.npad, L.lda, stride, U, W.info_c, W.ltbuf, W.resid, L.npad, s, &gen, &c0->exec);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(s, PS_SOLVE);
+        rc = sf_launch_logdet_z(W.C, L.npad, L.lda, stride, U, W.resid, L.npad, W.logdet, W.sqmah, s);
+        if (rc) return rc;
+        rc = sf_launch_finish(U, W.logdet, W.sqmah, W.info_e, W.info_c, d_lnl, d_info, s);
+        if (rc) return rc;
+    }
+    if (d_logdet) SF_HIP(hipMemcpyAsync(d_logdet, W.logdet, sizeof(double) * (size_t)U, hipMemcpyDeviceToDevice, s));
+    if (d_sqmah) SF_HIP(hipMemcpyAsync(d_sqmah, W.sqmah, sizeof(double) * (size_t)U, hipMemcpyDeviceToDevice, s));
     return SF_OK;
 }
 

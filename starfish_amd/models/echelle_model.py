@@ -26,6 +26,21 @@ class EchelleModel:
                        (list(v) if isinstance(v, (list, tuple)) else v))) for k, v in params.items()}
             self.orders.append(SpectrumModel(emulator, single, grid_params, device=dev, name=f"{name}[{i}]", **kw))
 
+    @classmethod
+    def from_orders(cls, models, name="EchelleModel"):
+        """Assemble from existing per-order :class:`SpectrumModel` objects (e.g. one emulator chunk per order,
+        per-order frozen local kernels).  All orders must expose the same thawed labels."""
+        self = cls.__new__(cls)
+        self.name = name
+        self.orders = list(models)
+        if not self.orders:
+            raise ValueError("EchelleModel needs at least one order")
+        labels = self.orders[0].labels
+        for m in self.orders[1:]:
+            if m.labels != labels:
+                raise ValueError(f"orders disagree on the thawed parameters: {m.labels} vs {labels}")
+        return self
+
     def __len__(self):
         return len(self.orders)
 
@@ -55,10 +70,46 @@ class EchelleModel:
             total += m.log_likelihood(None)
         return total
 
-    def log_likelihood_batch(self, P, priors=None):
-        """lnL (B,) for B shared parameter vectors: sum over orders of the batched per-order passes."""
+    def log_likelihood_batch(self, P, priors=None, return_info=False, return_orders=False):
+        """lnL (B,) for B shared parameter vectors.  All (order x walker) units of a device are evaluated in ONE
+        enqueue (``sf_loglike_multi_batch``: every order fills its own covariance matrices, all of them share one
+        batched Cholesky) with one host synchronisation per device; devices work concurrently.  The sum over
+        orders happens on the host (no collective).  Walkers that fail in any order get ``-inf``; ``info`` is the
+        first non-zero per-order code.  With ``return_orders`` the (n_orders, B) per-order values are returned too."""
+        from .. import _device as D
+
         P = np.atleast_2d(np.asarray(P, dtype=np.float64))
-        total = self.orders[0].log_likelihood_batch(P, priors)
-        for m in self.orders[1:]:
-            total = total + m.log_likelihood_batch(P, None)
-        return total
+        B = P.shape[0]
+        first = self.orders[0]
+        prior_lp = first._batch_prior(P, priors)
+        finite = np.isfinite(prior_lp)
+        lnl = np.full(B, -np.inf)
+        info = np.zeros(B, dtype=np.int32)
+        per_order = np.full((len(self.orders), B), -np.inf)
+        if finite.any():
+            packed = [m._pack(P[finite], update_caches=False) for m in self.orders]
+            by_dev = {}
+            for idx, (dev, md, rows) in enumerate(packed):
+                by_dev.setdefault(str(dev.dev), []).append(idx)
+            pending = []
+            for idxs in by_dev.values():  # enqueue on every device first, synchronise afterwards
+                devs = [packed[i][0] for i in idxs]
+                md = packed[idxs[0]][1]
+                pending.append((idxs, D.loglike_multi(devs, md, [packed[i][2] for i in idxs], sync=False)))
+            vals = np.zeros((len(self.orders), int(finite.sum())))
+            codes = np.zeros((len(self.orders), int(finite.sum())), dtype=np.int32)
+            for idxs, (quad, dinfo, sizes) in pending:
+                for i, out in zip(idxs, D.collect_multi(quad, dinfo, sizes)):
+                    vals[i] = out["lnl"]
+                    codes[i] = out["info"]
+            per_order[:, finite] = vals
+            lnl[finite] = vals.sum(axis=0) + prior_lp[finite]
+            bad = codes != 0
+            info[finite] = np.where(bad.any(axis=0), codes[bad.argmax(axis=0), np.arange(codes.shape[1])], 0)
+        self.last_info = info
+        out = (lnl,)
+        if return_info:
+            out += (info,)
+        if return_orders:
+            out += (per_order,)
+        return out if len(out) > 1 else lnl

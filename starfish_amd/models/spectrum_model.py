@@ -245,55 +245,43 @@ class SpectrumModel:
             raise ValueError("Param Vector does not match length of thawed parameters")
         self.set_param_dict(dict(zip(labels, params)))
 
+    # parameter groups: name -> attribute holding the hyper-parameter snapshot that freezing resets
+    _GROUPS = {"global_cov": "_glob_snapshot", "local_cov": "_loc_snapshot", "cheb": None}
+
+    def _group_members(self, group):
+        """Flat keys stored below a group, in storage order ('local_cov:0:mu', 'cheb:2', ...)."""
+        prefix = group + ":"
+        return [key for key in self.params.keys() if key.startswith(prefix)]
+
     def freeze(self, names):
-        """Remove parameters from the sampled vector; they keep their value (spectrum_model.py:495-549)."""
-        names = np.atleast_1d(names)
+        """Remove parameters from the sampled vector; they keep their value (spectrum_model.py:495-549).
+        A group name freezes all of its members and forgets the group's cached covariance; ``"all"``
+        freezes everything that is thawed and keeps the caches."""
+        names = [str(n) for n in np.atleast_1d(names)]
         if names[0] == "all":
-            for key in self.labels:
-                if key not in self.frozen:
-                    self.frozen.append(key)
-            for group in ("global_cov", "local_cov", "cheb"):
-                if group in self.params:
-                    self.frozen.append(group)
+            self.frozen += [key for key in self.labels if key not in self.frozen]
+            self.frozen += [group for group in self._GROUPS if group in self.params]
             return
-        for _name in names:
-            name = str(_name)
-            if name in ("global_cov", "cheb"):
+        for name in names:
+            if name in self._GROUPS:
                 self.frozen.append(name)
-                if name == "global_cov":
-                    self._glob_snapshot = None
-                for key in self.params.as_dict()[name].keys():
-                    flat = f"{name}:{key}"
-                    if flat not in self.frozen:
-                        self.frozen.append(flat)
-            elif name == "local_cov":
-                self.frozen.append("local_cov")
-                self._loc_snapshot = None
-                for i, kern in enumerate(self._local_kernels()):
-                    for key in kern.keys():
-                        flat = f"local_cov:{i}:{key}"
-                        if flat not in self.frozen:
-                            self.frozen.append(flat)
+                if self._GROUPS[name]:
+                    setattr(self, self._GROUPS[name], None)
+                self.frozen += [key for key in self._group_members(name) if key not in self.frozen]
             elif name not in self.frozen and name in self.params:
                 self.frozen.append(name)
 
     def thaw(self, names):
-        """Opposite of :meth:`freeze` (spectrum_model.py:551-590)."""
-        names = np.atleast_1d(names)
+        """Opposite of :meth:`freeze` (spectrum_model.py:551-590); thawing a group that is not frozen
+        raises ``ValueError`` like ``list.remove``."""
+        names = [str(n) for n in np.atleast_1d(names)]
         if names[0] == "all":
             self.frozen = []
             return
-        for _name in names:
-            name = str(_name)
-            if name in ("global_cov", "cheb"):
-                self.frozen.remove(name)
-                for key in self.params.as_dict()[name].keys():
-                    self.frozen.remove(f"{name}:{key}")
-            elif name == "local_cov":
-                self.frozen.remove("local_cov")
-                for i, kern in enumerate(self._local_kernels()):
-                    for key in kern.keys():
-                        self.frozen.remove(f"local_cov:{i}:{key}")
+        for name in names:
+            if name in self._GROUPS:
+                for key in [name, *self._group_members(name)]:
+                    self.frozen.remove(key)
             elif name in self.frozen:
                 self.frozen.remove(name)
 
@@ -411,12 +399,8 @@ class SpectrumModel:
         self._lnprob = float(out["lnl"][0])
         return self._lnprob + prior_lp
 
-    def log_likelihood_batch(self, P, priors=None, return_info=False):
-        """Log-posterior of B parameter vectors (rows of ``P`` in :attr:`labels` order) in one batched
-        device pass.  Walkers that fail (outside the emulator grid, vsini <= 0, non-positive-definite
-        covariance, non-finite prior) get ``-inf`` instead of raising; ``info`` carries the codes of
-        include/starfish_amd.h.  The model's own parameter state is not modified."""
-        P = np.atleast_2d(np.asarray(P, dtype=np.float64))
+    def _batch_prior(self, P, priors):
+        """Log-prior of every row of ``P`` (labels order); parameters not in ``labels`` use the current value."""
         labels = self.labels
         prior_lp = np.zeros(P.shape[0])
         if priors:
@@ -428,11 +412,22 @@ class SpectrumModel:
                     prior_lp += np.asarray(prior.logpdf(P[:, labels.index(key)]), dtype=np.float64)
                 else:
                     prior_lp += prior.logpdf(current[key])
+        return prior_lp
+
+    def log_likelihood_batch(self, P, priors=None, return_info=False):
+        """Log-posterior of B parameter vectors (rows of ``P`` in :attr:`labels` order) in one batched
+        device pass.  Walkers that fail (outside the emulator grid, vsini <= 0, non-positive-definite
+        covariance, non-finite prior) get ``-inf`` instead of raising; ``info`` carries the codes of
+        include/starfish_amd.h.  The model's own parameter state is not modified."""
+        P = np.atleast_2d(np.asarray(P, dtype=np.float64))
+        prior_lp = self._batch_prior(P, priors)
         finite = np.isfinite(prior_lp)
         lnl = np.full(P.shape[0], -np.inf)
         info = np.zeros(P.shape[0], dtype=np.int32)
         if finite.any():
-            dev, md, rows = self._pack(P[finite])
+            # (update_caches=False: a batch must not overwrite the hyper-parameter snapshots that a later
+            # freeze("all") + log_likelihood() of the model's OWN state relies on)
+            dev, md, rows = self._pack(P[finite], update_caches=False)
             out = dev.loglike(md, rows, solver=self.solver)
             lnl[finite] = out["lnl"] + prior_lp[finite]
             info[finite] = out["info"]

@@ -148,3 +148,67 @@ def vector_to_oracle_params(vec):
         cheb=[v["cheb:1"], v["cheb:2"]],
         grid=[v["T"], v["logg"], v["Z"]],
     )
+
+
+# ---------------------------------------------------------------------------------------------
+# Multi-order problems (cfg 3/4): independent orders, each a cfg-2 style order
+# with its own emulator chunk; stellar / calibration parameters are shared, every order keeps its own
+# (frozen) local kernel.
+SHARED_LABELS = tuple(k for k in LABELS if not k.startswith("local_cov"))
+
+
+def make_echelle(n_orders=25, N=3000, m=8, seed0=100):
+    """``n_orders`` synthetic orders starting at 5000 * 1.02**o Angstrom."""
+    return [make_order(N=N, m=m, seed=seed0 + o, wave0=5000.0 * 1.02**o) for o in range(n_orders)]
+
+
+def shared_ball(order0, B=64, seed=1):
+    """B shared parameter vectors (B, 10) in SHARED_LABELS order around the centre."""
+    keep = [i for i, k in enumerate(LABELS) if not k.startswith("local_cov")]
+    return walker_ball(order0, B=B, seed=seed)[:, keep]
+
+
+def shared_to_oracle_params(order, vec):
+    """SHARED_LABELS vector + the order's own fixed local kernel -> oracle parameter dict."""
+    c = centre_params(order)
+    v = dict(zip(SHARED_LABELS, vec))
+    return dict(
+        vz=v["vz"],
+        vsini=v["vsini"],
+        log_scale=v["log_scale"],
+        global_cov=(v["global_cov:log_amp"], v["global_cov:log_ls"]),
+        local_cov=[(k["mu"], k["log_amp"], k["log_sigma"]) for k in c["local_cov"]],
+        cheb=[v["cheb:1"], v["cheb:2"]],
+        grid=[v["T"], v["logg"], v["Z"]],
+    )
+
+
+def build_model(order, params=None, device=None, solver="dense", freeze=()):
+    """A product ``SpectrumModel`` (own ``Emulator`` + ``Spectrum``) for a synthetic order: the path a user
+    takes, including the model's own init-time resample of the emulator's bulk fluxes."""
+    from . import Spectrum
+    from .emulator import Emulator
+    from .models import SpectrumModel
+
+    emu = Emulator(order["grid_points"], order["param_names"], order["emu_wl"], order["weights"],
+                   order["eigenspectra"], order["w_hat"], order["flux_mean"], order["flux_std"], order["factors"])
+    emu._trained = True
+    data = Spectrum(order["wave"], order["flux"], sigmas=order["sigma"])
+    c = dict(centre_params(order)) if params is None else dict(params)
+    gp = c.pop("grid_params")
+    model = SpectrumModel(emu, data, grid_params=gp, device=device, solver=solver, **c)
+    for name in freeze:
+        model.freeze(name)
+    return model
+
+
+def build_echelle(orders, device=None, devices=None):
+    """Multi-order model over synthetic orders: shared stellar / calibration parameters, every order keeps its
+    own frozen local kernel (labels == SHARED_LABELS)."""
+    from .models import EchelleModel
+
+    models = []
+    for i, o in enumerate(orders):
+        dev = device if devices is None else devices[i % len(devices)]
+        models.append(build_model(o, device=dev, freeze=("local_cov",)))
+    return EchelleModel.from_orders(models)

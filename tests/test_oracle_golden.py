@@ -149,3 +149,17 @@ def test_ccm89_against_the_papers_table3():
     np.testing.assert_allclose(O.ccm89_a_lambda(w, 2.5), 2.5 * O.ccm89_a_lambda(w, 1.0), rtol=1e-14)
     f = np.ones((2, 50))
     np.testing.assert_array_equal(O.extinct_ccm89(w, f, 0.0), f)  # reference test: Av = 0 is the identity
+
+
+def test_oracle_matches_reference_cfg3_orders():
+    """cfg 3: the oracle against the reference's per-order values (two of the 25 orders, first walker)."""
+    g = load_golden("model_cfg3.npz")
+    orders = synth.make_echelle(int(g["n_orders"][0]), int(g["N"][0]), seed0=int(g["seed0"][0]))
+    for o in (0, 17):
+        oo = O.OracleOrder(
+            orders[o]["wave"], orders[o]["flux"], orders[o]["sigma"], orders[o]["emu_wl"], orders[o]["eigenspectra"],
+            orders[o]["flux_mean"], orders[o]["flux_std"], orders[o]["grid_points"], orders[o]["w_hat"],
+        )
+        got = O.log_likelihood(oo, synth.shared_to_oracle_params(orders[o], g["P"][0]))
+        want = g["lnl"][o, 0]
+        assert abs(got - want) <= 1e-8 * abs(want) + 1e-8, (o, got, want)

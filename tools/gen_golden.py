@@ -324,6 +324,28 @@ def gen_wasp14():
     print("model_wasp14.npz", ll)
 
 
+# ------------------------------------------------------------- cfg 3 (25 orders x N = 3000, shared walkers)
+def gen_cfg3(n_orders=25, N=3000, nwalk=3):
+    """Per-order lnL of the reference SpectrumModel for `nwalk` shared parameter vectors: the multi-order
+    likelihood is the sum over orders (docs/intro.rst:71-73; the reference's EchelleModel is a stub)."""
+    orders = synth.make_echelle(n_orders, N)
+    P = synth.shared_ball(orders[0], B=64)[:nwalk]
+    lnl = np.zeros((n_orders, nwalk))
+    for o, order in enumerate(orders):
+        model = ref_model(order)
+        model.freeze("local_cov")  # every order keeps its own local kernel; the walkers share the rest
+        assert tuple(model.labels) == synth.SHARED_LABELS, model.labels
+        for b, p in enumerate(P):
+            model.set_param_vector(p)
+            lnl[o, b] = model.log_likelihood()
+        print("  order", o, lnl[o])
+    np.savez_compressed(
+        os.path.join(OUT, "model_cfg3.npz"), P=P, lnl=lnl, labels=np.array(synth.SHARED_LABELS),
+        n_orders=np.array([n_orders]), N=np.array([N]), seed0=np.array([100]),
+    )
+    print("model_cfg3.npz", lnl.sum(axis=0))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     big = "--big" in sys.argv
@@ -344,6 +366,8 @@ if __name__ == "__main__":
         gen_wasp14()
     if want("large"):
         gen_model_large([1024, 3000], {1024: 8, 3000: 2}, "large")
+    if "cfg3" in only:
+        gen_cfg3()
     if big:
         gen_model_large([4096], {4096: 8}, "cfg2")
         gen_model_large([16384], {}, "cfg5")
