@@ -1,23 +1,35 @@
 #!/usr/bin/env python
 """
-bench.py -- headline benchmark of the log-likelihood hot path (BASELINE.json):
-log-likelihood evals/sec on a synthetic 4096-pixel order, batch = 128 walkers, fp64, per GPU.
+bench.py -- benchmark of the log-likelihood hot path (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--config cfg2|cfg3|cfg5] [--gpus N --steps K --warmup W] [--scaling weak|strong]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One STEP = one pass of the whole hot path (emulator query, transform chain, fused covariance fill,
-batched Cholesky, solve) over one batch of 128 walkers, parameters and static order data already
-resident in HBM.  Every rank works on its own batch of 128 walkers (weak scaling, no data-path
-collective: the walker x order units are independent); `value` = evals of all ranks / max-over-ranks
-time.  Rank 0 prints ONE JSON line which also carries
-  roofline     -- the dominant kernel (k_gemm_nt, the fp64 MFMA trailing update of the Cholesky):
-                  algorithmic flops of its launches / their HIP-event time on the launch stream
-  cpu_baseline -- the CPU oracle (numpy/scipy restatement == the reference's algorithm) timed on the
-                  host cores over a bounded sample of the same walkers (N = 1 only).
+Default = the headline: BASELINE cfg 2, log-likelihood evals/sec on a synthetic 4096-pixel order, batch = 128
+walkers, fp64.  One STEP = one pass of the whole hot path (emulator query, transform chain, fused covariance
+fill, batched Cholesky, solve) over one batch of (walker x order) units, parameters and static order data
+already resident in HBM.  The model is built through the product API (starfish_amd.Emulator / Spectrum /
+SpectrumModel / EchelleModel, including the model's own init-time resample); bench.py only skips the per-call
+host packing by keeping the packed parameter rows on the device.
+
+  cfg2   one order N = 4096, m = 8, B = 128 walkers, all 13 parameters thawed            (headline)
+  cfg3   25 orders x N = 3000, B = 64 shared walkers = 1600 units through sf_loglike_multi_batch
+         (cfg 4 = the same units sharded over ranks: --gpus N --scaling strong)
+  cfg5   one order N = 16384, B = 32
+
+Multi-GPU: the units are independent, every rank evaluates its own slice on its own GPU, no data-path
+collective.  --scaling weak (default): every rank gets a full batch; --scaling strong: the batch of the config
+is split over the ranks (128/G walkers per GPU).  `value` = units of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line which also carries
+  roofline     -- the dominant kernel (k_chol_panel, the fused fp64 MFMA panel step of the batched Cholesky):
+                  algorithmic flops of its launches / their HIP-event time on the launch streams
+  cpu_baseline -- the CPU oracle (numpy/scipy restatement == the reference's algorithm) timed on the host cores
+                  over a bounded sample of the same walkers (N = 1 only).  The oracle is imported ONLY there.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -25,11 +37,18 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (datasheet)
+HBM_PEAK_GBS = 8000.0
+
+CONFIGS = {
+    "cfg2": dict(npix=4096, batch=128, orders=1, label="cfg2: synthetic single order"),
+    "cfg3": dict(npix=3000, batch=64, orders=25, label="cfg3: multi-order model"),
+    "cfg5": dict(npix=16384, batch=32, orders=1, label="cfg5: long-order stress"),
+}
 
 
+# ------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_pool_worker(job):
     """cpu_baseline, pool mode: one walker through the CPU oracle in a fresh process with few BLAS threads
     (the reference's recommended way to use many cores: one process per chain / order, docs/intro.rst:71-73)."""
@@ -47,8 +66,9 @@ def _cpu_pool_worker(job):
         return val, time.perf_counter() - t0
 
 
-def _cpu_pool_baseline(oo_args, plist, max_procs=32, blas_threads=4, timeout=240):
-    """k walkers on a pool of processes; returns (evals/s, processes, threads/process, lnL values) or None."""
+def _cpu_pool_baseline(oo_args, plist, npix, blas_threads=4, timeout=300):
+    """One walker per process on ALL host cores (cpu_count / blas_threads processes, memory permitting);
+    returns (evals/s, processes, threads/process, lnL values, wall) or None."""
     import multiprocessing as mp
 
     try:
@@ -58,7 +78,8 @@ def _cpu_pool_baseline(oo_args, plist, max_procs=32, blas_threads=4, timeout=240
     except Exception:
         avail_gb = 64.0
     ncpu = os.cpu_count() or 1
-    procs = int(max(1, min(max_procs, len(plist), ncpu // max(1, blas_threads), avail_gb // 6)))
+    per_proc_gb = max(0.5, 12 * 8 * npix * npix / 2**30)  # ~a dozen N x N temporaries in the reference's algorithm
+    procs = int(max(1, min(len(plist), ncpu // max(1, blas_threads), avail_gb * 0.6 // per_proc_gb)))
     if procs < 2:
         return None
     ctx = mp.get_context("spawn")  # never fork a process that holds a HIP context
@@ -66,16 +87,79 @@ def _cpu_pool_baseline(oo_args, plist, max_procs=32, blas_threads=4, timeout=240
     from concurrent.futures import ProcessPoolExecutor
 
     try:
-        # (an executor, not multiprocessing.Pool: a worker that dies breaks the pool instead of being respawned)
         with ProcessPoolExecutor(max_workers=procs, mp_context=ctx) as ex:
             t0 = time.perf_counter()
             res = list(ex.map(_cpu_pool_worker, jobs, timeout=timeout))
             wall = time.perf_counter() - t0
     except Exception:
         return None
-    # throughput of the steady state: every process keeps evaluating walkers at its measured rate
-    per_eval = max(r[1] for r in res)
+    per_eval = max(r[1] for r in res)  # steady state: every process keeps evaluating at its measured rate
     return procs / per_eval, procs, blas_threads, [r[0] for r in res], wall
+
+
+def cpu_baseline(order, plist, lnl_gpu, args):
+    """The oracle (kind 'port') over walkers of the same batch: single process with the default BLAS threads, and a
+    pool over all cores; the better rate is `value`."""
+    import numpy as np
+
+    from oracle import sf_oracle as O  # test infrastructure: only the checker / CPU baseline may import it
+
+    oo_args = (order["wave"], order["flux"], order["sigma"], order["emu_wl"], order["eigenspectra"],
+               order["flux_mean"], order["flux_std"], order["grid_points"], order["w_hat"])
+    oo = O.OracleOrder(*oo_args)
+    k = min(args.cpu_sample, len(plist))
+    O.log_likelihood(oo, plist[0])  # warm the BLAS threads
+    tc = time.perf_counter()
+    want = np.array([O.log_likelihood(oo, p) for p in plist[:k]])
+    tcpu = time.perf_counter() - tc
+    rel = np.abs(lnl_gpu[:k] - want) / np.abs(want)
+    assert rel.max() < 1e-8, rel
+    try:
+        from threadpoolctl import threadpool_info
+
+        nthreads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        nthreads = os.cpu_count()
+    out = {
+        "value": k / tcpu, "unit": "evals/s", "cores": int(nthreads), "kind": "port",
+        "sample": f"first {k} walkers of the same batch (order 0) through oracle/sf_oracle.py (numpy/scipy, default "
+        f"BLAS threads; host has {os.cpu_count()} logical CPUs)",
+        "max_rel_dlnl_vs_gpu": float(rel.max()),
+    }
+    pool = None if args.no_cpu_pool else _cpu_pool_baseline(oo_args, plist, len(order["wave"]))
+    if pool is not None:
+        rate, procs, bt, vals, wall = pool
+        relp = np.abs(lnl_gpu[: len(vals)] - np.array(vals)) / np.abs(np.array(vals))
+        assert relp.max() < 1e-8, relp
+        out["single_process"] = {"value": k / tcpu, "cores": int(nthreads)}
+        out["process_pool"] = {
+            "value": rate, "processes": procs, "blas_threads_per_process": bt, "cores": procs * bt,
+            "wall_s_incl_startup": wall,
+            "note": "one walker per process, rate = processes / slowest per-eval time (steady state)",
+        }
+        if rate > k / tcpu:
+            out.update(
+                value=rate, cores=procs * bt,
+                sample=f"{procs} walkers of the same batch (order 0), one per process ({procs} processes x {bt} BLAS "
+                f"threads = all {os.cpu_count()} logical CPUs) through oracle/sf_oracle.py; single process with "
+                f"{int(nthreads)} BLAS threads: {k / tcpu:.2f} evals/s over {k} walkers",
+            )
+    return out
+
+
+# ------------------------------------------------------------------------------------------- workloads
+def perturb_grid(order, rng_seed=7):
+    """A wavelength grid that is NOT log-uniform (pixel spacing modulated by +-5 %, like a real rectified order):
+    the likelihood path then evaluates K_global per entry instead of from the per-diagonal table."""
+    import numpy as np
+
+    w = order["wave"]
+    n = len(w)
+    step = np.diff(w) * (1 + 0.05 * np.sin(np.arange(n - 1) / 37.0))
+    order = dict(order)
+    order["wave"] = np.concatenate([[w[0]], w[0] + np.cumsum(step)])
+    order["flux"] = 1 + 0.1 * np.sin(order["wave"] / 7) + 0.01 * np.random.default_rng(rng_seed).standard_normal(n)
+    return order
 
 
 def main():
@@ -83,8 +167,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--npix", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--npix", type=int, default=None, help="override the config's pixels per order")
+    ap.add_argument("--batch", type=int, default=None, help="override the config's walkers")
+    ap.add_argument("--orders", type=int, default=None, help="override the config's number of orders")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--grid", choices=["loguniform", "perturbed"], default="loguniform",
+                    help="perturbed: non log-uniform wavelengths (K_global evaluated per entry)")
     ap.add_argument("--profile-steps", type=int, default=1,
                     help="timed steps (the last ones) during which per-launch HIP events are recorded for `roofline`")
     ap.add_argument("--cpu-sample", type=int, default=8, help="walkers timed on the CPU oracle (0 = skip)")
@@ -109,151 +198,244 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == world
 
-    from gpu_helpers import device_order, oracle_order, pack_rows
     from starfish_amd import _device as D
-    from starfish_amd import synth
+    from starfish_amd import parallel, synth
 
-    N, B = args.npix, args.batch
-    order = synth.make_order(N=N)
-    oo = oracle_order(order)  # static arrays (bulk_fluxes, v11) shared by the HIP path and the oracle
-    do = device_order(oo)
-    P = synth.walker_ball(order, B=B, seed=1 + rank)  # each rank owns a different block of walkers
-    plist = [synth.vector_to_oracle_params(p) for p in P]
-    md, rows = pack_rows(do, plist)
-    P_dev = D.to_dev(rows, do.dev)
-    lnl = D.empty((B,), do.dev)
-    info = D.empty((B,), do.dev, torch.int32)
+    cfg = dict(CONFIGS[args.config])
+    custom = []
+    for key in ("npix", "batch", "orders"):
+        v = getattr(args, key)
+        if v is not None and v != cfg[key]:
+            cfg[key] = v
+            custom.append(f"{key}={v}")
+    N, B, n_orders = cfg["npix"], cfg["batch"], cfg["orders"]
+    units_full = B * n_orders  # units of one full batch of the config
+
+    # ---- build the model(s) through the product API and pack this rank's parameter rows
+    lib = None
+    if n_orders == 1:
+        order = synth.make_order(N=N)
+        if args.grid == "perturbed":
+            order = perturb_grid(order)
+        model = synth.build_model(order)
+        # weak: every rank its own B walkers (different seeds); strong: the config's B walkers split over the ranks
+        P_all = synth.walker_ball(order, B=B, seed=1 + (rank if args.scaling == "weak" else 0))
+        lo, hi = (0, B) if args.scaling == "weak" else parallel.shard_range(B, rank, world)
+        P = P_all[lo:hi]
+        dev, md, rows = model._pack(P, update_caches=False)
+        lib = dev.lib
+        P_dev = D.to_dev(rows, dev.dev)
+        n_local = hi - lo
+        lnl = D.empty((max(n_local, 1),), dev.dev)
+        info = D.empty((max(n_local, 1),), dev.dev, torch.int32)
+        nf = dev.nf
+        device = dev.dev
+
+        def step():
+            if n_local:
+                dev.loglike_device(md, P_dev, lnl[:n_local], info[:n_local])
+
+        def results():
+            return lnl[:n_local].cpu().numpy(), info[:n_local].cpu().numpy()
+
+        plist = [synth.vector_to_oracle_params(p) for p in P]
+        order0 = order
+    else:
+        orders = synth.make_echelle(n_orders, N)
+        if args.grid == "perturbed":
+            orders = [perturb_grid(o) for o in orders]
+        em = synth.build_echelle(orders)
+        P_all = synth.shared_ball(orders[0], B=B, seed=1 + (rank if args.scaling == "weak" else 0))
+        # order-major unit list (order o, walker w) -> this rank's contiguous slice keeps whole orders resident
+        lo, hi = (0, units_full) if args.scaling == "weak" else parallel.shard_range(units_full, rank, world)
+        segs_dev, segs_rows = [], []
+        for o, m in enumerate(em.orders):
+            wlo, whi = max(lo, o * B) - o * B, min(hi, (o + 1) * B) - o * B
+            if whi <= wlo:
+                continue
+            d_o, md, rows = m._pack(P_all[wlo:whi], update_caches=False)
+            segs_dev.append(d_o)
+            segs_rows.append(rows)
+        n_local = hi - lo
+        plan = D.MultiPlan(segs_dev, md, segs_rows) if segs_dev else None
+        lib = em.orders[0]._device().lib
+        nf = em.orders[0]._device().nf
+        device = em.orders[0]._device().dev
+
+        def step():
+            if plan is not None:
+                plan.enqueue()
+
+        def results():
+            if plan is None:
+                return np.zeros(0), np.zeros(0, dtype=np.int32)
+            outs = plan.collect()
+            return np.concatenate([o["lnl"] for o in outs]), np.concatenate([o["info"] for o in outs])
+
+        # CPU baseline sample: the walkers of order 0
+        first_rows = min(B, hi) - lo if lo < B else 0
+        plist = [synth.shared_to_oracle_params(orders[0], p) for p in P_all[:max(first_rows, 0)]]
+        order0 = orders[0]
 
     def barrier():
         if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
-        do.loglike_device(md, P_dev, lnl, info)
+        step()
     torch.cuda.synchronize()
-    do.lib.sf_profile_read(None, None, None, None)
+    lib.sf_profile_read(None, None, None, None)
     barrier()
     torch.cuda.synchronize()
     # one wave on its own stream samples the shader clock against the 100 MHz wall clock while the timed
     # steps run (sustained clock under this load; the datasheet peak assumes 2.4 GHz)
-    clk = torch.zeros(2, dtype=torch.int64, device=do.dev)
-    clk_stream = torch.cuda.Stream(device=do.dev)
+    clk = torch.zeros(2, dtype=torch.int64, device=device)
+    clk_stream = torch.cuda.Stream(device=device)
     # (skipped under torch.distributed: with RCCL initialised the spinning probe kernel serialises with the
     # main stream -- measured +40 ms on the timed region)
     if not use_dist and not os.environ.get("SF_BENCH_NO_CLOCK"):
-        do.lib.sf_debug_clock_probe(D.ptr(clk), 4_000_000, C.c_void_p(clk_stream.cuda_stream))
-    # HIP events on the launch stream around every k_gemm_nt launch (and every stage) are recorded during the
-    # LAST `--profile-steps` of the timed steps: 148 event records per step cost 0.5 ms/step (0.9 %), measured
+        lib.sf_debug_clock_probe(D.ptr(clk), 4_000_000, C.c_void_p(clk_stream.cuda_stream))
+    # HIP events on the launch streams around every panel-kernel launch (and every stage) are recorded during the
+    # LAST `--profile-steps` of the timed steps (the event records cost ~1 % of a step, measured)
     prof_steps = max(1, min(args.profile_steps, args.steps))
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - prof_steps:
-            do.lib.sf_profile_enable(1)
-        do.loglike_device(md, P_dev, lnl, info)
+            lib.sf_profile_enable(1)
+        step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    do.lib.sf_profile_enable(0)
+    lib.sf_profile_enable(0)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=do.dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only: the data path has no collective
     dt_max = float(t.item())
+    units_total = units_full * world if args.scaling == "weak" else units_full
 
     ms = (C.c_double * 6)()
     gflops, glaunch, gcalls = C.c_double(), C.c_long(), C.c_long()
-    do.lib.sf_profile_read(ms, C.byref(gflops), C.byref(glaunch), C.byref(gcalls))
-    lnl_host = lnl.cpu().numpy()
-    info_host = info.cpu().numpy()
+    lib.sf_profile_read(ms, C.byref(gflops), C.byref(glaunch), C.byref(gcalls))
+    lnl_host, info_host = results()
     assert (info_host == 0).all(), info_host
     assert np.isfinite(lnl_host).all()
 
-    # ---- secondary figure: the structure-exploiting solver (band + rank-m Woodbury) on
-    # the SAME walkers.  It is not the headline `value`: BASELINE's metric is the dense-covariance path.
+    # ---- secondary figure (single-order configs): the structure-exploiting solver (band + rank-m Woodbury,
+    # SURVEY.md 8 f-4) on the SAME walkers.  It is not the headline `value`: BASELINE's metric is the dense path.
     structured = None
-    hw = int(do.halfwidth_bound(md, rows).max())
-    if not args.no_structured and 0 <= hw <= do.banded_max_halfwidth():
-        lnl_b = D.empty((B,), do.dev)
-        info_b = D.empty((B,), do.dev, torch.int32)
-        ksteps = max(args.steps, 10)
-        for _ in range(2):
-            do.loglike_banded_device(md, P_dev, hw, lnl_b, info_b)
-        torch.cuda.synchronize()
-        do.lib.sf_profile_read(None, None, None, None)
-        do.lib.sf_profile_enable(1)
-        barrier()
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        for _ in range(ksteps):
-            do.loglike_banded_device(md, P_dev, hw, lnl_b, info_b)
-        torch.cuda.synchronize()
-        barrier()
-        dtb = time.perf_counter() - tb
-        do.lib.sf_profile_enable(0)
-        tt = torch.tensor([dtb], dtype=torch.float64, device=do.dev)
-        if use_dist:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dtb = float(tt.item())
-        msb = (C.c_double * 6)()
-        do.lib.sf_profile_read(msb, None, None, None)
-        lb = lnl_b.cpu().numpy()
-        assert (info_b.cpu().numpy() == 0).all()
-        rel_b = float(np.max(np.abs(lb - lnl_host) / np.abs(lnl_host)))
-        assert rel_b < 1e-9, rel_b
-        structured = {
-            "value": B * world * ksteps / dtb,
-            "unit": "evals/s",
-            "ms_per_step": dtb / ksteps * 1e3,
-            "steps": ksteps,
-            "band_halfwidth_px": hw,
-            "max_rel_dlnl_vs_dense_path": rel_b,
-            "stage_ms_per_step": {
-                "transforms": msb[0] / ksteps, "band_fill": msb[1] / ksteps,
-                "band_cholesky_forms": msb[3] / ksteps, "woodbury_finish": msb[4] / ksteps,
-            },
-            "note": "sf_loglike_banded_batch: C = band + Y^T Y never formed; same lnL to rounding; O(N W^2) flops, "
-            "so the dense MFMA roofline above does not apply to it",
-        }
+    if n_orders == 1 and not args.no_structured and n_local:
+        hw = int(dev.halfwidth_bound(md, rows).max())
+        if 0 <= hw <= dev.banded_max_halfwidth():
+            lnl_b = D.empty((n_local,), dev.dev)
+            info_b = D.empty((n_local,), dev.dev, torch.int32)
+            ksteps = max(args.steps, 10)
+            for _ in range(2):
+                dev.loglike_banded_device(md, P_dev, hw, lnl_b, info_b)
+            torch.cuda.synchronize()
+            lib.sf_profile_read(None, None, None, None)
+            lib.sf_profile_enable(1)
+            barrier()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(ksteps):
+                dev.loglike_banded_device(md, P_dev, hw, lnl_b, info_b)
+            torch.cuda.synchronize()
+            barrier()
+            dtb = time.perf_counter() - tb
+            lib.sf_profile_enable(0)
+            tt = torch.tensor([dtb], dtype=torch.float64, device=dev.dev)
+            if use_dist:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtb = float(tt.item())
+            msb = (C.c_double * 6)()
+            lib.sf_profile_read(msb, None, None, None)
+            lb = lnl_b.cpu().numpy()
+            assert (info_b.cpu().numpy() == 0).all()
+            rel_b = float(np.max(np.abs(lb - lnl_host) / np.abs(lnl_host)))
+            assert rel_b < 1e-9, rel_b
+            # roofline of the sweep kernel: the band is read once from HBM; MFMA floor from the per-column block count
+            n16 = (N + 15) // 16 * 16
+            band_bytes = n_local * n16 * ((hw + 2) & ~1) * 8.0
+            sweep_s = msb[3] / ksteps * 1e-3
+            nbr = (hw + 15) // 16 + 1
+            mfma_per_col = nbr * (nbr + 1) / 2 + 2 * nbr + 2 * (1 + 8) + 24  # window pairs + solves + rhs rows + 16x16 potrf/inverse
+            floor_s = mfma_per_col * 64 / 4 * (n16 / 16) / 2.4e9 * max(1.0, n_local / 256.0)
+            structured = {
+                "value": n_local * world * ksteps / dtb, "unit": "evals/s", "ms_per_step": dtb / ksteps * 1e3,
+                "steps": ksteps, "band_halfwidth_px": hw, "max_rel_dlnl_vs_dense_path": rel_b,
+                "stage_ms_per_step": {
+                    "transforms": msb[0] / ksteps, "band_fill": msb[1] / ksteps,
+                    "band_cholesky_forms": msb[3] / ksteps, "woodbury_finish": msb[4] / ksteps,
+                },
+                "roofline": {
+                    "kernel": "k_band_forms (LDS-window banded Cholesky + forward substitutions, one workgroup per "
+                    "matrix or per half matrix)",
+                    "bound": "latency (sequential 16-column chain per matrix); HBM and MFMA floors for reference",
+                    "hbm": {"bytes_per_step": band_bytes, "achieved": band_bytes / sweep_s / 1e9 if sweep_s > 0 else None,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": band_bytes / sweep_s / 1e9 / HBM_PEAK_GBS if sweep_s > 0 else None},
+                    "mfma_floor_ms": floor_s * 1e3, "sweep_ms": sweep_s * 1e3,
+                    "frac_of_mfma_floor": floor_s / sweep_s if sweep_s > 0 else None,
+                },
+                "note": "sf_loglike_banded_batch: C = band + Y^T Y never formed; same lnL to rounding; O(N W^2) flops, "
+                "so the dense MFMA roofline above does not apply to it",
+            }
 
     if rank == 0:
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 as
-        # the micro-arch guide prescribes for gfx950, + WRITE_SIZE), summarised under profiles/ by
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 as the
+        # micro-arch guide prescribes for gfx950, + WRITE_SIZE) summarised under profiles/ by
         # tools/summarize_profile.py; bench.py cannot collect counters itself.
-        import glob
-
         traffic, traffic_src = None, None
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))[-1:]:
-            if N == 4096 and B == 128:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r02_*{args.config}*_pmc_summary.json")))[-1:]:
+            if not custom and args.grid == "loguniform":
                 with open(f) as fh:
-                    traffic = json.load(fh)["_k_gemm_nt_all"]["hbm_bytes_per_launch"]
-                traffic_src = os.path.relpath(f, ROOT)
+                    summ = json.load(fh)
+                key = "_k_chol_panel_all" if "_k_chol_panel_all" in summ else None
+                if key:
+                    traffic = summ[key]["hbm_bytes_per_launch"]
+                    traffic_src = os.path.relpath(f, ROOT)
         ticks, wall = clk.cpu().tolist()
         clock_mhz = 100.0 * ticks / wall if wall else 0.0
         gemm_s = ms[2] * 1e-3
         achieved = gflops.value / gemm_s / 1e12 if gemm_s > 0 else 0.0
         flops_eval = N**3 / 3 + 2 * 8 * N**2 + N**2
+        label = cfg["label"] + (" [custom: " + ", ".join(custom) + "]" if custom else "")
+        if n_orders == 1:
+            workload = (f"{label} N_pix={N}, 8 eigenspectra, M=27, N_f={nf}, 1 global + 1 local kernel, all 13 "
+                        f"parameters thawed, batch={B} walkers" + (" per GPU" if args.scaling == "weak" else " in total"))
+            metric = f"log-likelihood evals/sec, {N}-pixel order, batch={B} walkers"
+        else:
+            workload = (f"{label}: {n_orders} echelle orders x N_pix={N}, 8 eigenspectra, M=27, N_f={nf}, shared walkers "
+                        f"batch={B} (10 thawed parameters, every order its own local kernel) = {units_full} (order x walker) "
+                        "units" + (" per GPU" if args.scaling == "weak" else " in total") + ", one sf_loglike_multi_batch pass")
+            metric = f"single-order log-likelihood evals/sec (order x walker units), {n_orders} orders x {N} pixels, batch={B} walkers"
+        if args.grid == "perturbed":
+            workload += "; NON log-uniform wavelength grid (K_global per entry)"
         out = {
-            "metric": "log-likelihood evals/sec, 4096-pixel order, batch=128 walkers",
-            "value": B * world * args.steps / dt_max,
+            "metric": metric,
+            "value": units_total * args.steps / dt_max,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"cfg2: synthetic single order N_pix={N}, 8 eigenspectra, M=27, N_f={do.nf}, "
-                f"1 global + 1 local kernel, all 13 parameters thawed, batch={B} walkers per GPU",
-                "global_batch": B * world,
-                "parallelism": f"walker-sharded x{world}, no collective",
+                "workload": workload,
+                "global_batch": units_total,
+                "units_per_gpu": n_local,
+                "parallelism": f"(order x walker) units sharded x{world}, no collective",
             },
-            "whole_path_tflops": B * world * args.steps * flops_eval / dt_max / 1e12,
+            "whole_path_tflops": units_total * args.steps * flops_eval / dt_max / 1e12,
+            "whole_path_frac_of_mfma_peak": units_total * args.steps * flops_eval / dt_max / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
             "roofline": {
-                "kernel": "k_gemm_nt (v_mfma_f64_16x16x4_f64 trailing update of the batched Cholesky)",
+                "kernel": "k_chol_panel (fused v_mfma_f64_16x16x4_f64 panel step of the batched Cholesky: long-K update "
+                "+ triangular solve + diagonal-tile update)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -263,9 +445,10 @@ def main():
                 "peak_at_sustained_clock": FP64_MFMA_PEAK_TFLOPS * clock_mhz / 2400.0 if clock_mhz else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "note": "k_gemm_nt launches run on two streams (lookahead) and overlap: `achieved` divides by the "
-                "UNION of the launch intervals (HIP events, common origin, recorded during the last `profiled_steps` of "
-                "the timed steps); avg_launch_ms is the plain mean launch duration (what rocprofv3 --stats reports)",
+                "note": "the panel launches run on several streams (lookahead chain, slab groups) and overlap: `achieved` "
+                "divides by the UNION of the launch intervals (HIP events, common origin, recorded during the last "
+                "`profiled_steps` of the timed steps); avg_launch_ms is the plain mean launch duration (what rocprofv3 "
+                "--stats reports)",
                 "profiled_steps": prof_steps,
                 "launches": int(glaunch.value),
                 "avg_launch_ms": ms[5] / max(1, glaunch.value),
@@ -274,58 +457,13 @@ def main():
             },
             "stage_ms_per_step": {
                 k: v / prof_steps
-                for k, v in zip(["transforms", "fill", "gemm_union", "potrf_stage", "solve", "gemm_launches_sum"], ms)
+                for k, v in zip(["transforms", "fill", "panel_union", "potrf_stage", "solve", "panel_launches_sum"], ms)
             },
-            "potrf_stage_tflops": B * prof_steps * (N**3 / 3) / (ms[3] * 1e-3) / 1e12 if ms[3] > 0 else None,
+            "potrf_stage_tflops": n_local * prof_steps * (N**3 / 3) / (ms[3] * 1e-3) / 1e12 if ms[3] > 0 else None,
             "structured_solver": structured,
         }
-        if world == 1 and args.cpu_sample > 0:
-            from oracle import sf_oracle as O
-
-            k = min(args.cpu_sample, B)
-            O.log_likelihood(oo, plist[0])  # warm the BLAS threads
-            tc = time.perf_counter()
-            want = np.array([O.log_likelihood(oo, p) for p in plist[:k]])
-            tcpu = time.perf_counter() - tc
-            rel = np.abs(lnl_host[:k] - want) / np.abs(want)
-            try:
-                from threadpoolctl import threadpool_info
-
-                nthreads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-            except Exception:
-                nthreads = os.cpu_count()
-            out["cpu_baseline"] = {
-                "value": k / tcpu,
-                "unit": "evals/s",
-                "cores": int(nthreads),
-                "kind": "port",
-                "sample": f"first {k} walkers of the same batch through oracle/sf_oracle.py "
-                f"(numpy/scipy, default BLAS threads; host has {os.cpu_count()} logical CPUs)",
-                "max_rel_dlnl_vs_gpu": float(rel.max()),
-            }
-            # second mode: many processes with few BLAS threads each (how the reference is meant to use a
-            # many-core host); the better of the two is the reported value
-            oo_args = (order["wave"], order["flux"], order["sigma"], order["emu_wl"], order["eigenspectra"],
-                       order["flux_mean"], order["flux_std"], order["grid_points"], order["w_hat"])
-            pool = None if args.no_cpu_pool else _cpu_pool_baseline(oo_args, plist)
-            if pool is not None:
-                rate, procs, bt, vals, wall = pool
-                relp = np.abs(lnl_host[: len(vals)] - np.array(vals)) / np.abs(np.array(vals))
-                assert relp.max() < 1e-8, relp
-                out["cpu_baseline"]["single_process"] = {"value": k / tcpu, "cores": int(nthreads)}
-                out["cpu_baseline"]["process_pool"] = {
-                    "value": rate, "processes": procs, "blas_threads_per_process": bt, "cores": procs * bt,
-                    "wall_s_incl_startup": wall,
-                    "note": "one walker per process, rate = processes / slowest per-eval time (steady state)",
-                }
-                if rate > k / tcpu:
-                    out["cpu_baseline"].update(
-                        value=rate, cores=procs * bt,
-                        sample=f"{procs} walkers of the same batch, one per process ({procs} processes x {bt} BLAS "
-                        f"threads) through oracle/sf_oracle.py; single process with {int(nthreads)} BLAS threads: "
-                        f"{k / tcpu:.2f} evals/s over {k} walkers (host has {os.cpu_count()} logical CPUs)",
-                    )
-            assert rel.max() < 1e-8, rel
+        if world == 1 and args.cpu_sample > 0 and plist:
+            out["cpu_baseline"] = cpu_baseline(order0, plist, lnl_host, args)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -87,72 +87,97 @@ def band_halfwidth_bound(wave, rows, n_grid, has_global, n_local, n_cheb):
     return np.minimum(hw, big).astype(np.int64)
 
 
+class MultiPlan:
+    """Device-resident state of a repeated multi-order evaluation (sf_loglike_multi_batch): parameter rows,
+    outputs and workspace are allocated once; :meth:`enqueue` only launches.  ``orders`` are
+    :class:`DeviceOrder` objects of ONE device, ``rows_list[i]`` the (B_i, stride) C-ABI rows of order i.
+    Unit lists that do not fit the free HBM (or ``max_units``) are cut into several calls."""
+
+    def __init__(self, orders, md, rows_list, max_units=None):
+        torch = _torch()
+        self.orders = list(orders)
+        self.md = md
+        self.lib = orders[0].lib
+        self.dev = orders[0].dev
+        if any(o.dev != self.dev for o in orders):
+            raise ValueError("multi-order call: all orders must live on the same device")
+        self.sizes = [int(np.atleast_2d(r).shape[0]) if not torch.is_tensor(r) else int(r.shape[0]) for r in rows_list]
+        U = sum(self.sizes)
+        with torch.cuda.device(self.dev):
+            self.P = [r if torch.is_tensor(r) else to_dev(np.atleast_2d(r), self.dev) for r in rows_list]
+            self.quad = empty((4, U), self.dev)  # lnl, logdet, sqmah, log_scale: one device->host copy
+            self.info = empty((U,), self.dev, torch.int32)
+            one = _lib.Segment(orders[0].ctx, ptr(self.P[0]).value, 1, 0)
+            # units that fit: the workspace is linear in the unit count up to the fixed Cholesky scratch
+            w1 = self.lib.sf_multi_workspace_bytes(C.byref(one), 1, C.byref(md))
+            one.B = 2
+            w2 = self.lib.sf_multi_workspace_bytes(C.byref(one), 1, C.byref(md))
+            per_unit = max(w2 - w1, 1)
+            free, _total = torch.cuda.mem_get_info(self.dev)
+            lead = orders[0]
+            if lead._ws_multi is not None:
+                free += lead._ws_multi.numel()
+            cap = max(1, (int(free * 0.85) - (w1 - per_unit)) // per_unit)
+            if max_units:
+                cap = min(cap, int(max_units))
+            self.pieces, cur, cur_n = [], [], 0
+            for i, n in enumerate(self.sizes):
+                lo = 0
+                while lo < n:
+                    take = min(n - lo, cap - cur_n)
+                    cur.append((i, lo, lo + take))
+                    cur_n += take
+                    lo += take
+                    if cur_n == cap:
+                        self.pieces.append(cur)
+                        cur, cur_n = [], 0
+            if cur:
+                self.pieces.append(cur)
+            offs = np.concatenate([[0], np.cumsum(self.sizes)])
+            self.calls, need = [], 0
+            for piece in self.pieces:
+                segs = (_lib.Segment * len(piece))()
+                for k, (i, lo, hi) in enumerate(piece):
+                    segs[k] = _lib.Segment(orders[i].ctx, ptr(self.P[i][lo:hi]).value, hi - lo, 0)
+                nb = self.lib.sf_multi_workspace_bytes(segs, len(piece), C.byref(md))
+                if nb == 0:
+                    _lib.check(-1, "sf_multi_workspace_bytes")
+                need = max(need, nb)
+                u0 = int(offs[piece[0][0]] + piece[0][1])  # the pieces of one call are contiguous in unit order
+                self.calls.append((segs, len(piece), u0, sum(hi - lo for _, lo, hi in piece)))
+            if lead._ws_multi is None or lead._ws_multi.numel() < need:
+                lead._ws_multi = None
+                lead._ws_multi = workspace(need, self.dev)
+            self.ws = lead._ws_multi
+
+    @property
+    def units(self):
+        return sum(self.sizes)
+
+    def enqueue(self):
+        """Launch only: results land in ``self.quad`` / ``self.info`` once the device's current stream is done."""
+        torch = _torch()
+        with torch.cuda.device(self.dev):
+            s = stream_ptr(self.dev)
+            q = self.quad
+            for segs, nseg, u0, n in self.calls:
+                rc = self.lib.sf_loglike_multi_batch(
+                    segs, nseg, C.byref(self.md), ptr(q[0][u0:u0 + n]), ptr(q[1][u0:u0 + n]), ptr(q[2][u0:u0 + n]),
+                    ptr(q[3][u0:u0 + n]), ptr(self.info[u0:u0 + n]), ptr(self.ws), self.ws.numel(), s,
+                )
+                _lib.check(rc, "sf_loglike_multi_batch")
+
+    def collect(self):
+        return collect_multi(self.quad, self.info, self.sizes)
+
+
 def loglike_multi(orders, md, rows_list, max_units=None, sync=True):
-    """(order x walker) units of several orders of ONE device in one enqueue and one host synchronisation
-    (sf_loglike_multi_batch): ``orders`` are :class:`DeviceOrder` objects, ``rows_list[i]`` the (B_i, stride)
-    C-ABI parameter rows of order i.  Returns a list of dicts (lnl, logdet, sqmah, log_scale, info) per order.
-    Batches that do not fit the free HBM (or ``max_units``) are evaluated in chunks of whole-order slices.
-    With ``sync=False`` the device tensors are returned un-synchronised as (quad, info, sizes) for callers
-    that overlap several devices (:func:`collect_multi` finishes the job)."""
-    torch = _torch()
-    lib = orders[0].lib
-    dev = orders[0].dev
-    if any(o.dev != dev for o in orders):
-        raise ValueError("loglike_multi: all orders must live on the same device")
-    sizes = [int(np.atleast_2d(r).shape[0]) for r in rows_list]
-    U = sum(sizes)
-    with torch.cuda.device(dev):
-        P = [r if torch.is_tensor(r) else to_dev(np.atleast_2d(r), dev) for r in rows_list]
-        quad = empty((4, U), dev)
-        info = empty((U,), dev, torch.int32)
-        s = stream_ptr(dev)
-        # chunk plan: consecutive (order, row range) pieces whose workspace fits
-        one = _lib.Segment(orders[0].ctx, ptr(P[0]).value, 1, 0)
-        per_unit = lib.sf_multi_workspace_bytes(C.byref(one), 1, C.byref(md))
-        free, _total = torch.cuda.mem_get_info(dev)
-        ws_old = orders[0]._ws_multi
-        if ws_old is not None:
-            free += ws_old.numel()
-        cap = max(1, int(free * 0.85) // max(per_unit, 1))
-        if max_units:
-            cap = min(cap, int(max_units))
-        pieces, cur, cur_n = [], [], 0
-        for i, n in enumerate(sizes):
-            lo = 0
-            while lo < n:
-                take = min(n - lo, cap - cur_n)
-                cur.append((i, lo, lo + take))
-                cur_n += take
-                lo += take
-                if cur_n == cap:
-                    pieces.append(cur)
-                    cur, cur_n = [], 0
-        if cur:
-            pieces.append(cur)
-        offs = np.concatenate([[0], np.cumsum(sizes)])
-        for piece in pieces:
-            segs = (_lib.Segment * len(piece))()
-            for k, (i, lo, hi) in enumerate(piece):
-                segs[k] = _lib.Segment(orders[i].ctx, ptr(P[i][lo:hi]).value, hi - lo, 0)
-            need = lib.sf_multi_workspace_bytes(segs, len(piece), C.byref(md))
-            if need == 0:
-                _lib.check(-1, "sf_multi_workspace_bytes")
-            ws = orders[0]._ws_multi
-            if ws is None or ws.numel() < need:
-                orders[0]._ws_multi = None
-                ws = orders[0]._ws_multi = workspace(need, dev)
-            # the pieces of one call are contiguous in unit order
-            u0 = int(offs[piece[0][0]] + piece[0][1])
-            n_units = sum(hi - lo for _, lo, hi in piece)
-            rc = lib.sf_loglike_multi_batch(
-                segs, len(piece), C.byref(md), ptr(quad[0][u0:u0 + n_units]), ptr(quad[1][u0:u0 + n_units]),
-                ptr(quad[2][u0:u0 + n_units]), ptr(quad[3][u0:u0 + n_units]), ptr(info[u0:u0 + n_units]),
-                ptr(ws), ws.numel(), s,
-            )
-            _lib.check(rc, "sf_loglike_multi_batch")
-        if not sync:
-            return quad, info, sizes
-        return collect_multi(quad, info, sizes)
+    """(order x walker) units of several orders of ONE device in one enqueue and one host synchronisation.
+    Returns a list of dicts (lnl, logdet, sqmah, log_scale, info) per order; with ``sync=False`` the
+    un-synchronised :class:`MultiPlan` (callers overlapping several devices call ``plan.collect()`` later)."""
+    plan = MultiPlan(orders, md, rows_list, max_units=max_units)
+    plan.enqueue()
+    return plan.collect() if sync else plan
 
 
 def collect_multi(quad, info, sizes):

@@ -981,7 +981,9 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;  // rows wm*32.., cols wn*64..
+    // rows wm*32.., cols wn*64..; waves w and w + 4 share a SIMD: they get different column halves, because in
+    // the triangular solve the two halves have different amounts of work
+    const int wm = w >> 1, wn = (w ^ (w >> 2)) & 1;
     const int l15 = lane & 15, lq = lane >> 4;
     double* Cb = g.C + (int64_t)b * g.sC;
 
@@ -1220,79 +1222,82 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
     }
 
     // -------------------------------------------------------------------- 4: S = C[slab, slab] - L L^T
-    // 36 lower blocks on 8 waves (5 + 4 per wave pair, see sf_syrk_diag_tile) in two passes of 3 + 2 blocks per
-    // wave: the L accumulators stay live while their chunks are dumped, 5 more blocks do not fit the budget
+    // The L slab just stored is read back (L2) through the ordinary operand staging -- the accumulators are free
+    // by now, so the 36 lower blocks fit one pass of 5 + 4 blocks per wave pair (see sf_syrk_diag_tile); keeping
+    // L in registers and dumping it chunk by chunk needed two passes and 16 barriers.
     {
         const int p = w >> 1, h = w & 1;
-        const int nch = (g.skip & 2) ? 0 : pw >> 5;
+        int bi[5], bj[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (h == 0) {
+                bi[q] = 7 - p;
+                bj[q] = q;
+            } else {
+                const int n_hi = 3 - p;  // blocks 5 .. 7-p of row 7-p, then blocks 0 .. p of row p
+                const int qq = q < 4 ? q : 0;
+                bi[q] = qq < n_hi ? 7 - p : p;
+                bj[q] = qq < n_hi ? 5 + qq : qq - n_hi;
+            }
+        }
+        const int nstore = h == 0 ? 5 : 4;
+        const int nk2 = (g.skip & 2) ? 0 : pw / GK;
+        const int lr = tid >> 3, lc = (tid & 7) * 2;
+        const double* Lp[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) Lp[q] = Cb + (int64_t)(row0 + min(lr + 64 * q, rows_here - 1)) * g.lda + k0 + lc;
+        double2 rl[2];
+        auto gload2 = [&](int kt) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) rl[q] = *(const double2*)(Lp[q] + kt * GK);
+        };
+        auto lstore2 = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                double* pa = &As[buf][(lr + 64 * q) * GLD + lc];
+                pa[0] = rl[q].x;
+                pa[1] = rl[q].y;
+            }
+        };
+        __syncthreads();  // the L slab is visible to every wave of the workgroup; the LDS buffers are free
+        if (nk2 > 0) gload2(0);
         const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
+        sf_d4 acc2[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
+                acc2[q][r] = (q < nstore && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
+            }
+        if (nk2 > 0) lstore2(0);
+        __syncthreads();
+        auto compute2 = [&](int cur) {
+            const double* S = &As[cur][l15 * GLD + lq];
+#pragma unroll
+            for (int ks = 0; ks < GK / 4; ++ks) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[bi[q] * 16 * GLD + ks * 4], S[bj[q] * 16 * GLD + ks * 4],
+                                                                   acc2[q], 0, 0, 1);  // neg:[1,0,0]
+            }
+        };
+        for (int kt = 0; kt + 1 < nk2; ++kt) {
+            gload2(kt + 1);
+            compute2(kt & 1);
+            lstore2((kt & 1) ^ 1);
+            __syncthreads();
+        }
+        if (nk2 > 0) compute2((nk2 - 1) & 1);
         double* So = g.Sout ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
         const int ldo = g.Sout ? g.ldS : g.lda;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            constexpr int NQ = 3;
-            const int nq = pass ? 2 : 3, q0 = pass ? 3 : 0;
-            int bi[NQ], bj[NQ];
+        for (int q = 0; q < 5; ++q) {
+            if (q >= nstore) continue;
 #pragma unroll
-            for (int qq = 0; qq < NQ; ++qq) {
-                const int q = q0 + (qq < nq ? qq : 0);
-                if (h == 0) {
-                    bi[qq] = 7 - p;
-                    bj[qq] = q;
-                } else {
-                    const int n_hi = 3 - p;  // blocks 5 .. 7-p of row 7-p, then blocks 0 .. p of row p
-                    const int qx = q < 4 ? q : 0;
-                    bi[qq] = qx < n_hi ? 7 - p : p;
-                    bj[qq] = qx < n_hi ? 5 + qx : qx - n_hi;
-                }
-            }
-            const int nstore = (h == 1 && pass == 1) ? 1 : nq;  // (h == 1 owns 4 blocks: q = 4 is a spare)
-            sf_d4 acc2[NQ];
-#pragma unroll
-            for (int qq = 0; qq < NQ; ++qq)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * bi[qq] + lq + 4 * r, col = 16 * bj[qq] + l15;
-                    acc2[qq][r] = (qq < nstore && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
-                }
-#pragma unroll
-            for (int q = 0; q < GT / 32; ++q) {
-                if (q >= nch) continue;
-                __syncthreads();
-                if (wn == (q >> 1)) {  // chunk q of L (columns 32 q ..) from the accumulators of its owner waves
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        if (half != (q & 1)) continue;
-#pragma unroll
-                        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-                            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    Ach[(wm * (16 * TM) + mi * 16 + lq + 4 * r) * CLD + nn * 16 + l15] =
-                                        acc[mi][2 * half + nn][r];
-                    }
-                }
-                __syncthreads();
-                const double* S = &Ach[l15 * CLD + lq];
-#pragma unroll 2
-                for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-                    for (int qq = 0; qq < NQ; ++qq) {
-                        if (qq >= nq) continue;
-                        acc2[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[bi[qq] * 16 * CLD + ks * 4], S[bj[qq] * 16 * CLD + ks * 4],
-                                                                        acc2[qq], 0, 0, 1);  // neg:[1,0,0]
-                    }
-                }
-            }
-#pragma unroll
-            for (int qq = 0; qq < NQ; ++qq) {
-                if (qq >= nstore) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * bi[qq] + lq + 4 * r, col = 16 * bj[qq] + l15;
-                    if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[qq][r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
+                if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[q][r];
             }
         }
     }

@@ -98,8 +98,8 @@ class EchelleModel:
                 pending.append((idxs, D.loglike_multi(devs, md, [packed[i][2] for i in idxs], sync=False)))
             vals = np.zeros((len(self.orders), int(finite.sum())))
             codes = np.zeros((len(self.orders), int(finite.sum())), dtype=np.int32)
-            for idxs, (quad, dinfo, sizes) in pending:
-                for i, out in zip(idxs, D.collect_multi(quad, dinfo, sizes)):
+            for idxs, plan in pending:
+                for i, out in zip(idxs, plan.collect()):
                     vals[i] = out["lnl"]
                     codes[i] = out["info"]
             per_order[:, finite] = vals
