@@ -373,8 +373,12 @@ struct sf_ctx {
     double dv = 0.0, wave_max = 0.0;
     DevBuf wave, flux, sigma, knots, spec, tw, Lf, Uf, rdiag, coef_static, inv_band;
     DevBuf grid, variances, lengthscales, gmin, gmax, alpha, Linv;
-    sf_exec exec;  // side / auxiliary streams and the event pool of this context's launch sequences
-    ~sf_ctx() { sf_exec_release(&exec); }
+    sf_exec exec;        // side / auxiliary streams and the event pool of this context's launch sequences
+    sf_exec exec_potrf;  // multi-order calls: the factorisation's own streams / events (exec pipelines the fills)
+    ~sf_ctx() {
+        sf_exec_release(&exec);
+        sf_exec_release(&exec_potrf);
+    }
 };
 
 static double min_dv(const double* w, int n) {  // Starfish/utils.py:22
@@ -633,15 +637,17 @@ struct Work {
     double2* fft;
     int *info_e, *info_c;
     unsigned char* tilemap;
-    size_t bytes;
+    size_t bytes, ltbuf_stride;
     Layout L;
 };
 // B units of per-unit buffers; the transient buffers of the transform chain (used by one launch sequence at a
 // time, stream ordered) are sized for Bt walkers
-static Work carve(const Layout& L, const sf_model_desc* mdl, int B, int Bt, void* p, size_t cap, bool need_C) {
+static Work carve(const Layout& L, const sf_model_desc* mdl, int B, int Bt, void* p, size_t cap, bool need_C,
+                  int potrf_units = 0, int potrf_slots = 1) {
     Carve k(p, cap);
     Work w;
     w.L = L;
+    if (potrf_units <= 0) potrf_units = B;
     const size_t b = (size_t)B, bt = (size_t)Bt;
     w.mu = k.take<double>(b * L.m);
     w.Lw = k.take<double>(b * L.m * L.m);
@@ -661,7 +667,8 @@ static Work carve(const Layout& L, const sf_model_desc* mdl, int B, int Bt, void
     w.resid = k.take<double>(b * L.npad);
     w.Y = k.take<double>(b * L.mpad * L.npad);
     w.ztrsv = k.take<double>(b * L.npad);
-    w.ltbuf = need_C ? k.take<double>(sf_potrf_work_doubles(L.npad, B)) : nullptr;  // Cholesky scratch
+    w.ltbuf_stride = sf_align_up(sf_potrf_work_doubles(L.npad, potrf_units), 32);
+    w.ltbuf = need_C ? k.take<double>(w.ltbuf_stride * potrf_slots) : nullptr;  // Cholesky scratch (per concurrent call)
     w.tilemap = need_C ? k.take<unsigned char>(b * tilemap_bytes(L)) : nullptr;
     w.gtab = need_C ? k.take<double>(b * (size_t)L.npad) : nullptr;
     w.C = need_C ? k.take<double>(b * (size_t)L.npad * L.lda) : nullptr;
@@ -1034,11 +1041,18 @@ static int multi_layout(const sf_segment* segs, int nseg, const sf_model_desc* m
     *bmax = bm;
     return SF_OK;
 }
+// chunks of a multi-order call: whole segments, at least this many units (enough matrices to keep the launches of
+// a factorisation full); two factorisations run at a time
+static int multi_min_units(int U) {
+    static const int nchunks = getenv("SF_MULTI_CHUNKS") ? std::max(1, atoi(getenv("SF_MULTI_CHUNKS"))) : 2;  // tuning aid (1, 2, 3, 4 chunks: 283.1, 282.1, 282.7, 283.9 ms at cfg 3)
+    return std::max(256, (U + nchunks - 1) / nchunks);
+}
+static int multi_chunk_cap(int U, int bmax) { return std::min(U, multi_min_units(U) + bmax); }
 extern "C" size_t sf_multi_workspace_bytes(const sf_segment* segs, int nseg, const sf_model_desc* mdl) {
     Layout L;
     int U = 0, bmax = 0;
     if (multi_layout(segs, nseg, mdl, &L, &U, &bmax)) return 0;
-    return carve(L, mdl, U, bmax, nullptr, 0, true).bytes;
+    return carve(L, mdl, U, bmax, nullptr, 0, true, multi_chunk_cap(U, bmax), 1).bytes;
 }
 extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf_model_desc* mdl, double* d_lnl,
                                       double* d_logdet, double* d_sqmah, double* d_log_scale, int* d_info,
@@ -1051,7 +1065,7 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
         sf_set_error("sf_loglike_multi_batch: d_lnl and a workspace are required");
         return SF_EINVAL;
     }
-    const size_t need = carve(L, mdl, U, bmax, nullptr, 0, true).bytes;
+    const size_t need = carve(L, mdl, U, bmax, nullptr, 0, true, multi_chunk_cap(U, bmax), 1).bytes;
     if (work_bytes < need) {
         sf_set_error("workspace too small: have %zu, need %zu", work_bytes, need);
         return SF_ENOMEM;
@@ -1059,23 +1073,42 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
     sf_ctx* c0 = segs[0].ctx;
     if (use_device(c0)) return SF_EHIP;
     hipStream_t s = (hipStream_t)stream;
-    Work W = carve(L, mdl, U, bmax, d_work, work_bytes, true);
+    Work W = carve(L, mdl, U, bmax, d_work, work_bytes, true, multi_chunk_cap(U, bmax), 1);
     prof_count_call();
     const int64_t stride = (int64_t)L.npad * L.lda;
     const int nt128 = (L.npad + 127) / 128;
-    int u0 = 0;
+    // Pipeline: the per-order transform chains and fills (many small launches, a few per cent of the step) run on
+    // the context's auxiliary stream one chunk of orders ahead of the factorisation on the caller's stream, so all
+    // but the first chunk's are hidden behind the Cholesky of the previous chunk.  Chunks are whole segments of
+    // at least `min_units` units (enough matrices to keep the factorisation's launches full).
+    sf_exec* ex = &c0->exec;
+    rc = sf_exec_prepare(ex);
+    if (rc) return rc;
+    static const bool no_pipe = getenv("SF_MULTI_NO_PIPELINE") != nullptr;  // tuning aid
+    hipStream_t sp = no_pipe ? s : ex->aux;
+    const int min_units = multi_min_units(U);
+    if (sp != s) {
+        SF_HIP(hipEventRecord(ex->fork, s));
+        SF_HIP(hipStreamWaitEvent(sp, ex->fork, 0));
+    }
+    struct Chunk {
+        int u0, units;
+        hipEvent_t filled;
+    };
+    std::vector<Chunk> chunks;
+    int u0 = 0, cu0 = 0;
     for (int i = 0; i < nseg; ++i) {
         sf_ctx* c = segs[i].ctx;
         const int B = segs[i].B;
         Work w = slice(W, u0);
         {
-            ProfScope ps(s, PS_TRANSFORM);
+            ProfScope ps(sp, PS_TRANSFORM);
             rc = run_transforms(c, mdl, B, segs[i].d_params, w, nullptr, nullptr, nullptr,
-                                d_log_scale ? d_log_scale + u0 : nullptr, true, s);
+                                d_log_scale ? d_log_scale + u0 : nullptr, true, sp);
             if (rc) return rc;
         }
         {
-            ProfScope ps(s, PS_FILL);
+            ProfScope ps(sp, PS_FILL);
             sf_fill_args f = fill_args(c, mdl, segs[i].d_params, w);
             f.C = w.C;
             f.lda = L.lda;
@@ -1085,28 +1118,47 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
             f.gtab = w.gtab;
             f.tilemap = w.tilemap;
             f.nt128 = nt128;
-            rc = sf_launch_fill(f, B, s);
+            rc = sf_launch_fill(f, B, sp);
             if (rc) return rc;
         }
         u0 += B;
+        if (u0 - cu0 >= min_units || i == nseg - 1) {
+            Chunk ch{cu0, u0 - cu0, nullptr};
+            if (sp != s) {
+                rc = sf_exec_event(ex, &ch.filled);
+                if (rc) return rc;
+                SF_HIP(hipEventRecord(ch.filled, sp));
+            }
+            chunks.push_back(ch);
+            cu0 = u0;
+        }
     }
-    {
-        ProfScope ps(s, PS_POTRF);
-        sf_gen_args gen;
-        gen.Y = W.Y;
-        gen.mpad = L.mpad;
-        gen.ldy = L.npad;
-        gen.tilemap = W.tilemap;
-        gen.nt128 = nt128;
-        rc = sf_launch_potrf(W.C, L.npad, L.lda, stride, U, W.info_c, W.ltbuf, W.resid, L.npad, s, &gen, &c0->exec);
-        if (rc) return rc;
-    }
-    {
-        ProfScope ps(s, PS_SOLVE);
-        rc = sf_launch_logdet_z(W.C, L.npad, L.lda, stride, U, W.resid, L.npad, W.logdet, W.sqmah, s);
-        if (rc) return rc;
-        rc = sf_launch_finish(U, W.logdet, W.sqmah, W.info_e, W.info_c, d_lnl, d_info, s);
-        if (rc) return rc;
+    // (sf_launch_potrf rewinds the event pool of the executor it is given: the factorisation uses its own.
+    // Two factorisations in flight on two streams, to hide one's under-filled last panels behind the other, were
+    // measured slower: 306 vs 291 ms at cfg 3.)
+    for (const Chunk& ch : chunks) {
+        if (ch.filled) SF_HIP(hipStreamWaitEvent(s, ch.filled, 0));
+        Work w = slice(W, ch.u0);
+        {
+            ProfScope ps(s, PS_POTRF);
+            sf_gen_args gen;
+            gen.Y = w.Y;
+            gen.mpad = L.mpad;
+            gen.ldy = L.npad;
+            gen.tilemap = w.tilemap;
+            gen.nt128 = nt128;
+            rc = sf_launch_potrf(w.C, L.npad, L.lda, stride, ch.units, w.info_c, W.ltbuf, w.resid, L.npad, s, &gen,
+                                 &c0->exec_potrf);
+            if (rc) return rc;
+        }
+        {
+            ProfScope ps(s, PS_SOLVE);
+            rc = sf_launch_logdet_z(w.C, L.npad, L.lda, stride, ch.units, w.resid, L.npad, w.logdet, w.sqmah, s);
+            if (rc) return rc;
+            rc = sf_launch_finish(ch.units, w.logdet, w.sqmah, w.info_e, w.info_c, d_lnl + ch.u0,
+                                  d_info ? d_info + ch.u0 : nullptr, s);
+            if (rc) return rc;
+        }
     }
     if (d_logdet) SF_HIP(hipMemcpyAsync(d_logdet, W.logdet, sizeof(double) * (size_t)U, hipMemcpyDeviceToDevice, s));
     if (d_sqmah) SF_HIP(hipMemcpyAsync(d_sqmah, W.sqmah, sizeof(double) * (size_t)U, hipMemcpyDeviceToDevice, s));
