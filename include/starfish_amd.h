@@ -59,6 +59,9 @@ extern "C" {
 #define SF_INFO_INTERNAL (-5)    /* banded solver only: a wave-synchronisation wait inside the sweep timed out;
                                     cannot happen by construction (the bound keeps a logic error from hanging the GPU) */
 
+#define SF_INFO_NAN (-6)         /* the likelihood came out NaN although every stage reported success: lnl = -inf, but
+                                    distinguishable from a legitimately rejected walker */
+
 #define SF_JITTER 1e-10 /* spectrum_model.py:399 */
 
 const char* sf_version(void);
@@ -159,6 +162,12 @@ typedef struct sf_order_desc {
     const double* lengthscales; /* [m*n_grid]                                                */
     const double* v11;          /* [(m*M)^2]  emulator.py:123-128                            */
     const double* w_hat;        /* [m*M]      component-major (emulator/_utils.py:19-21)     */
+    /* optional (both or neither): the factor of the constant v11, so that callers holding many orders of
+     * one emulator factor it once (LAPACK) instead of once per context.  linv = inverse of the LOWER
+     * Cholesky factor of v11, row-major with zeros above the diagonal; alpha = v11^-1 w_hat.
+     * NULL: computed by sf_ctx_create on the host (scalar code: fine up to m*M of a few hundred). */
+    const double* linv;         /* [(m*M)^2] or NULL                                         */
+    const double* alpha;        /* [m*M] or NULL                                             */
 } sf_order_desc;
 
 sf_ctx* sf_ctx_create(const sf_order_desc* desc, int device, int* err);

@@ -15,6 +15,7 @@ INFO_MESSAGES = {
     -3: "emulator weight covariance is not positive definite",
     -4: "covariance support wider than the band half-width given to the banded solver",
     -5: "internal error: the banded sweep's wave synchronisation timed out (please report)",
+    -6: "the log-likelihood evaluated to NaN (non-finite input or intermediate)",
 }
 INFO_BANDWIDTH = -4
 C_KMS = 2.99792458e5
@@ -85,6 +86,18 @@ def band_halfwidth_bound(wave, rows, n_grid, has_global, n_local, n_cheb):
         step = C_KMS / np.abs(mu) * float(np.min(np.diff(w)))
         hw = np.maximum(hw, np.floor(2 * r0 / step * (1 + 1e-9)) + 1)
     return np.minimum(hw, big).astype(np.int64)
+
+
+def factor_v11(v11, w_hat):
+    """Init-time constants of the emulator conditional (the reference solves with the constant v11 on every call,
+    emulator.py:387-388): Linv = inverse of the lower Cholesky factor of v11 and alpha = v11^-1 w_hat, by LAPACK on
+    the host, once per hyper-parameter set -- every order context of the emulator receives the same arrays."""
+    from scipy.linalg import cho_solve, cholesky, solve_triangular
+
+    L = cholesky(np.asarray(v11, dtype=np.float64), lower=True)
+    linv = np.tril(solve_triangular(L, np.eye(L.shape[0]), lower=True))
+    alpha = cho_solve((L, True), np.asarray(w_hat, dtype=np.float64))
+    return np.ascontiguousarray(linv), np.ascontiguousarray(alpha)
 
 
 class MultiPlan:
@@ -207,7 +220,10 @@ class DeviceOrder:
         v11,
         w_hat,
         device=None,
+        emu_factor=None,
     ):
+        """``emu_factor``: optional ``(Linv, alpha)`` of the constant v11 (see :func:`factor_v11`), shared by all
+        orders of one emulator; without it the library factors v11 itself (scalar host code)."""
         self.lib = _lib.require_gpu()
         torch = _torch()
         self.dev = device_of(device)
@@ -238,6 +254,11 @@ class DeviceOrder:
         d.min_dv_wave, d.bulk_fluxes = _lib.as_double_p(mdw), _lib.as_double_p(bulk)
         d.grid_points, d.variances = _lib.as_double_p(grid), _lib.as_double_p(var)
         d.lengthscales, d.v11, d.w_hat = map(_lib.as_double_p, (ls, v11a, wh))
+        if emu_factor is not None:
+            linv, alpha = f8(emu_factor[0]), f8(emu_factor[1])
+            assert linv.shape == v11a.shape and alpha.shape == (v11a.shape[0],)
+            self._keep += [linv, alpha]
+            d.linv, d.alpha = _lib.as_double_p(linv), _lib.as_double_p(alpha)
         err = C.c_int(0)
         with torch.cuda.device(self.dev):
             self.ctx = self.lib.sf_ctx_create(C.byref(d), self.dev.index or 0, C.byref(err))
@@ -406,7 +427,16 @@ class DeviceOrder:
                 out["info"][idx] = info.cpu().numpy()
                 if want_resid:
                     out["resid"][idx] = resid.cpu().numpy()
-        rest = np.nonzero(~fits | (out["info"] == INFO_BANDWIDTH))[0] if solver == "auto" else np.array([], dtype=int)
+        rest = np.array([], dtype=int)
+        if solver == "auto":
+            # too wide for the banded kernels -> dense; an internal wait timeout (-5, cannot happen by construction) is
+            # recomputed by the dense solver too instead of silently turning into a rejected walker
+            internal = out["info"] == -5
+            if internal.any():
+                import warnings
+
+                warnings.warn(f"banded solver: internal status -5 for {int(internal.sum())} walker(s); recomputed densely")
+            rest = np.nonzero(~fits | (out["info"] == INFO_BANDWIDTH) | internal)[0]
         if rest.size:
             dense = self.loglike(md, rows[rest], want_resid=want_resid, max_chunk=max_chunk, solver="dense")
             for key in out:

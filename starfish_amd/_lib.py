@@ -34,6 +34,8 @@ class OrderDesc(C.Structure):
         ("lengthscales", c_double_p),
         ("v11", c_double_p),
         ("w_hat", c_double_p),
+        ("linv", c_double_p),
+        ("alpha", c_double_p),
     ]
 
 

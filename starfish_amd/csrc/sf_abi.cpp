@@ -566,7 +566,17 @@ extern "C" sf_ctx* sf_ctx_create(const sf_order_desc* d, int device, int* err) {
     {
         const int N = d->m * d->M;
         std::vector<double> alpha, Linv, gmin(d->n_grid), gmax(d->n_grid);
-        TRY(emulator_constants(d->v11, d->w_hat, N, alpha, Linv));
+        if ((d->linv != nullptr) != (d->alpha != nullptr)) {
+            sf_set_error("sf_ctx_create: linv and alpha must be given together");
+            delete c;
+            return fail(SF_EINVAL);
+        }
+        if (d->linv) {
+            Linv.assign(d->linv, d->linv + (size_t)N * N);
+            alpha.assign(d->alpha, d->alpha + N);
+        } else {
+            TRY(emulator_constants(d->v11, d->w_hat, N, alpha, Linv));
+        }
         for (int p = 0; p < d->n_grid; ++p) {
             gmin[p] = gmax[p] = d->grid_points[p];
             for (int j = 1; j < d->M; ++j) {
@@ -1250,7 +1260,7 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         f.add_jitter = 1;
         f.npad = (c->n + 15) / 16 * 16;
         const bool wide = halfwidth > sf_band_max_halfwidth(c->m + 1);
-        rc = sf_launch_band_fill(f, B, bw.band, wide ? bw.ldb : halfwidth + 1, bw.ldb, sband, w.info_c, bw.gtab, sf);
+        rc = sf_launch_band_fill(f, B, bw.band, wide ? bw.ldb : halfwidth + 1, halfwidth, bw.ldb, sband, w.info_c, bw.gtab, sf);
         if (rc) return rc;
     }
     if (sf != s) SF_HIP(hipEventRecord(aux->join, sf));

@@ -108,8 +108,8 @@ struct sf_fill_args {
 };
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);
 // band storage of the structured part of C (sf_band.hip consumes it); a.npad = rows written (>= a.n)
-int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int ldb, int64_t sband, int* info,
-                        double* gtab, hipStream_t s);  // gtab: B x (ws+1) scratch or NULL
+int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int halfwidth, int ldb, int64_t sband,
+                        int* info, double* gtab, hipStream_t s);  // ws stored diagonals > halfwidth; gtab: B x (ws+1) or NULL
 int sf_launch_global_cov(const double* wave, int n, double amp, double ls, double* out, hipStream_t s);
 int sf_launch_local_cov(const double* wave, int n, double amp, double mu, double sigma, int accumulate,
                         double* out, hipStream_t s);

@@ -280,9 +280,10 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
 
 // Band storage of Bd = diag(sigma^2) + K_global + sum K_local + jitter for the structure-exploiting
 // solver (sf_band.hip): band[i*ldb + d] = Bd[i][i-d], d in [0, ws).  The element formulas and their
-// order of additions are those of k_fill_tiles.  A thread on the last stored diagonal also probes the
-// first diagonal outside the storage: a non-zero there means the caller's half-width is too small
-// for this walker -> info = SF_INFO_BANDWIDTH (the result would silently drop covariance otherwise).
+// order of additions are those of k_fill_tiles.  Diagonals d > hw (the caller's half-width) are stored as
+// zeros; the thread on diagonal hw also probes diagonal hw + 1: a non-zero there means the caller's
+// half-width is too small for this walker -> info = SF_INFO_BANDWIDTH (the result would silently drop
+// covariance otherwise) -- independently of how many diagonals the storage happens to hold.
 // The element formulas are those of sf_matern_elem / sf_local_elem with the per-walker divisions
 // hoisted into reciprocals and cos(pi x) evaluated as cospi(x) (differences ~1e-16 relative, far inside
 // the 1e-10 covariance tolerance; the dense fill keeps the reference's exact operation order).
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void k_band_gtab(sf_fill_args a, double* __res
 }
 
 #define SF_BF_ROWS 32
-__global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __restrict__ band, int ws, int ldb,
+__global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __restrict__ band, int ws, int hw, int ldb,
                                                    int64_t sband, int* __restrict__ info,
                                                    const double* __restrict__ gtab) {
     // per-walker constants once per block: exp() of the hyper-parameters (spectrum_model.py:343-357)
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __res
         for (int d = lane; d < ws; d += 64) {
             const int j = i - d;
             double v = 0.0;
-            if (j >= 0) {
+            if (j >= 0 && d <= hw) {  // diagonals past the caller's half-width are stored as zeros, never as data
                 bool any = false;
                 const double k = structured(j, any);
                 if (d == 0) {
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __res
                 } else {
                     v = k;
                 }
-                if (d == ws - 1 && j >= 1) {
-                    // first diagonal outside the storage: non-zero -> the caller's half-width is too small
+                if (d == hw && j >= 1) {
+                    // first diagonal past the caller's half-width (whatever the storage width): non-zero -> too small
                     bool outside = false;
                     (void)structured(j - 1, outside);
                     if (outside) atomicCAS(info + b, 0, SF_INFO_BANDWIDTH);
@@ -399,8 +400,12 @@ __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __res
     }
 }
 
-int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int ldb, int64_t sband, int* info,
-                        double* gtab, hipStream_t s) {
+int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int halfwidth, int ldb, int64_t sband,
+                        int* info, double* gtab, hipStream_t s) {
+    if (halfwidth < 0 || halfwidth >= ws) {
+        sf_set_error("band fill: half-width %d does not fit the %d stored diagonals", halfwidth, ws);
+        return SF_EINVAL;
+    }
     if (a.n_local > SF_MAX_LOCAL) {
         sf_set_error("at most %d local kernels are supported", SF_MAX_LOCAL);
         return SF_EINVAL;
@@ -414,7 +419,7 @@ int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int 
         hipLaunchKernelGGL(k_band_gtab, dim3((ws + 256) / 256, B), dim3(256), 0, s, a, gtab, ws);
         SF_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_band_fill, dim3((unsigned)((a.npad + SF_BF_ROWS - 1) / SF_BF_ROWS), B), dim3(256), 0, s, a, band, ws, ldb, sband,
+    hipLaunchKernelGGL(k_band_fill, dim3((unsigned)((a.npad + SF_BF_ROWS - 1) / SF_BF_ROWS), B), dim3(256), 0, s, a, band, ws, halfwidth, ldb, sband,
                        info, table ? (const double*)gtab : nullptr);
     SF_LAUNCH_CHECK();
     return SF_OK;

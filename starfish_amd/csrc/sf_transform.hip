@@ -881,7 +881,8 @@ __global__ void k_finish(int B, const double* __restrict__ logdet, const double*
     int code = info ? info[b] : 0;
     if (code == 0 && info2) code = info2[b];
     double v = -(logdet[b] + sqmah[b]) / 2;
-    if (code != 0 || !(v == v)) v = -INFINITY;
+    if (code == 0 && !(v == v)) code = SF_INFO_NAN;
+    if (code != 0) v = -INFINITY;
     lnl[b] = v;
     if (info_out) info_out[b] = code;
 }

@@ -80,6 +80,14 @@ class Emulator:
             self.grid_points, self.grid_points, self.variances, self.lengthscales
         )
         self._device = None  # the device-side factor of v11 is rebuilt lazily
+        self._factor = None
+
+    def v11_factor(self):
+        """(Linv, alpha) of the current v11, computed once per hyper-parameter set and handed to every order
+        context built on this emulator."""
+        if self._factor is None:
+            self._factor = D.factor_v11(self.v11, self.w_hat)
+        return self._factor
 
     @property
     def lambda_xi(self):
@@ -137,7 +145,7 @@ class Emulator:
             z = np.zeros(0)
             self._device = D.DeviceOrder(
                 z, z, z, z, np.zeros((0, 0)), self.grid_points, self.variances, self.lengthscales,
-                self.v11, self.w_hat,
+                self.v11, self.w_hat, emu_factor=self.v11_factor(),
             )
         return self._device
 
@@ -219,9 +227,11 @@ class Emulator:
         while chunk // 2 > inside.size:
             chunk //= 2
         if chunk < len(wl):
-            centre = (inside[0] + inside[-1]) // 2
+            # the reference centres the window on the grid point nearest to the middle of the requested range
+            # (grid_tools/utils.py:223-227) and asserts that it covers the range; where that window would leave
+            # the grid or cut an end off, it is slid instead of failing
+            centre = int(np.abs(wl - (wl_min + wl_max) / 2.0).argmin())
             lo = min(max(centre - chunk // 2, 0), len(wl) - chunk)
-            # the window must contain the requested range; slide it if the centring cut an end off
             lo = min(lo, inside[0])
             lo = max(lo, inside[-1] + 1 - chunk)
             sel = slice(lo, lo + chunk)

@@ -107,7 +107,7 @@ class SpectrumModel:
             self._dev = D.DeviceOrder(
                 self.data.wave, self.data.flux, self.data.sigma, self.min_dv_wave, self.bulk_fluxes,
                 emu.grid_points, emu.variances, emu.lengthscales, emu.v11, emu.w_hat,
-                device=self._device_index,
+                device=self._device_index, emu_factor=emu.v11_factor(),
             )
             self._dev_v11 = emu.v11
         return self._dev

@@ -20,8 +20,9 @@ def _log_grid(dv, start, end):
     return 10 ** (lo + (hi - lo) / (n - 1) * np.arange(n))
 
 
-def make_order(N=4096, m=8, seed=0, dv=2.0, wave0=5000.0, pad=20.0):
-    """One echelle order of N pixels and a matching m-component emulator over a 3x3x3 grid."""
+def make_order(N=4096, m=8, seed=0, dv=2.0, wave0=5000.0, pad=20.0, grid_axes=None):
+    """One echelle order of N pixels and a matching m-component emulator over a 3x3x3 library grid
+    (``grid_axes``: other axis values, e.g. the 11 x 6 x 5 = 330 points of BIG_GRID_AXES)."""
     rng = np.random.default_rng(seed)
     wave = wave0 * np.exp(np.arange(N) * dv / C_KMS)
     emu_wl = _log_grid(dv, wave.min() - pad, wave.max() + pad)
@@ -30,9 +31,8 @@ def make_order(N=4096, m=8, seed=0, dv=2.0, wave0=5000.0, pad=20.0):
     eig = np.ascontiguousarray(q.T)
     flux_mean = 1 + 0.1 * np.sin(emu_wl / 7)
     flux_std = 0.05 + 0.01 * np.cos(emu_wl / 3)
-    grid = np.array(
-        list(product((6000.0, 6100.0, 6200.0), (4.0, 4.5, 5.0), (-1.0, -0.5, 0.0)))
-    )
+    axes = grid_axes or ((6000.0, 6100.0, 6200.0), (4.0, 4.5, 5.0), (-1.0, -0.5, 0.0))
+    grid = np.array(list(product(*axes)))
     M = len(grid)
     weights = rng.standard_normal((M, m))
     fluxes = weights @ eig
@@ -56,6 +56,14 @@ def make_order(N=4096, m=8, seed=0, dv=2.0, wave0=5000.0, pad=20.0):
         w_hat=w_hat,
         factors=np.ones(M),
     )
+
+
+# a library of the size of the reference's worked example (examples/setup.ipynb:47,185: m = 4, M = 330 -> m M = 1320)
+BIG_GRID_AXES = (
+    tuple(5700.0 + 100.0 * i for i in range(11)),
+    tuple(3.5 + 0.5 * i for i in range(6)),
+    tuple(-2.0 + 0.5 * i for i in range(5)),
+)
 
 
 def centre_params(order):

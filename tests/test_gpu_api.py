@@ -234,3 +234,29 @@ def test_emulator_train_improves_likelihood():
     before = emu.log_likelihood()
     emu.train(options=dict(maxiter=40))
     assert emu.log_likelihood() >= before
+
+
+def test_realistic_emulator_size_vs_reference():
+    """a library of the reference's worked-example size (m = 4, M = 330 -> m M = 1320,
+    examples/setup.ipynb:47,185): Emulator.__call__ and the model likelihood against the reference's values."""
+    g = load_golden("emulator_big.npz")
+    o = synth.make_order(N=256, m=4, seed=13, grid_axes=synth.BIG_GRID_AXES)
+    assert len(o["grid_points"]) == 330
+    m = build(o)
+    emu = m.emulator
+    np.testing.assert_allclose(np.trace(emu.v11), g["v11_trace"][0], rtol=1e-13)
+    np.testing.assert_allclose(emu.v11[::97, ::101], g["v11_sample"], rtol=1e-12, atol=1e-300)
+    for i, q in enumerate(g["queries"]):
+        mu, cov = emu(q)
+        np.testing.assert_allclose(mu, g[f"mu_{i}"], rtol=1e-9, atol=1e-9 * np.abs(g[f"mu_{i}"]).max())
+        np.testing.assert_allclose(cov, g[f"cov_{i}"], rtol=1e-9, atol=1e-9 * np.abs(g[f"cov_{i}"]).max())
+    assert close(m.log_likelihood(), g["lnl"][0])
+    got = m.log_likelihood_batch(g["batch_P"])
+    assert all(close(a, b) for a, b in zip(got, g["batch_lnl"]))
+    # the library's own (scalar host) factorisation of v11 gives the same constants as the LAPACK factor handed in
+    from starfish_amd import _device as D
+
+    dev = m._device()
+    plain = D.DeviceOrder(*dev._keep[:10])
+    md, rows = m._pack(g["batch_P"], update_caches=False)[1:]
+    np.testing.assert_allclose(plain.loglike(md, rows)["lnl"], dev.loglike(md, rows)["lnl"], rtol=1e-12)

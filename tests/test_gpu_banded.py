@@ -301,3 +301,37 @@ def test_auto_solver_fuzz_ragged_sizes(N):
     np.testing.assert_allclose(auto["sqmah"], dense["sqmah"], rtol=1e-8)
     b = int(np.argmax(hw))
     assert close_lnl(auto["lnl"][b], O.log_likelihood(oo, plist[b]))
+
+
+def test_wide_band_halfwidth_slightly_too_small_is_flagged():
+    """a half-width that is too small by a few pixels must give info = -4 in the wide (in-place) path as
+    well -- the probe sits on the first diagonal past the CALLER's half-width, not past the storage width, and
+    nothing beyond the caller's half-width is stored."""
+    import torch
+
+    o = synth.make_order(N=1024)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    p = synth.vector_to_oracle_params(synth.walker_ball(o, B=1)[0])
+    p["global_cov"] = (p["global_cov"][0], float(np.log(25.0)))
+    p["local_cov"] = []
+    md, rows = pack_rows(do, [p])
+    # exact support of the global kernel on this grid: largest pixel offset with r <= r0 = 6 ls (kernels.py:27-33)
+    w = o["wave"]
+    r0 = 6 * 25.0
+    d = np.arange(1, 1024)
+    r = 2.99792458e5 / 2 * (w[d] - w[0]) / (w[d] + w[0])
+    support = int(d[r <= r0].max())
+    assert support > do.banded_window_halfwidth()
+    P = D.to_dev(rows, do.dev)
+    lnl = D.empty((1,), do.dev)
+    info = D.empty((1,), do.dev, torch.int32)
+    dense = do.loglike(md, rows)["lnl"][0]
+    for short in (1, 2, 7, 20):
+        do.loglike_banded_device(md, P, support - short, lnl, info)
+        assert info.cpu().numpy()[0] == D.INFO_BANDWIDTH, short
+        assert lnl.cpu().numpy()[0] == -np.inf
+    for extra in (0, 1, 13):
+        do.loglike_banded_device(md, P, support + extra, lnl, info)
+        assert info.cpu().numpy()[0] == 0, extra
+        np.testing.assert_allclose(lnl.cpu().numpy()[0], dense, rtol=1e-10)

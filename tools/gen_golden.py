@@ -204,6 +204,31 @@ def gen_emulator():
     print("emulator.npz", len(out))
 
 
+def gen_emulator_big():
+    """Library of the size of the reference's worked example: m = 4, M = 330 (m M = 1320)."""
+    o = synth.make_order(N=256, m=4, seed=13, grid_axes=synth.BIG_GRID_AXES)
+    emu, _ = ref_objects(o)
+    out = {"v11_trace": np.array([np.trace(emu.v11)]), "v11_sum": np.array([emu.v11.sum()]),
+           "v11_sample": emu.v11[::97, ::101].copy()}
+    queries = np.array([[6050.0, 4.2, -0.3], [6200.0, 4.5, -0.5], [5700.0, 3.5, -2.0], [6699.0, 5.99, -0.01]])
+    out["queries"] = queries
+    for i, q in enumerate(queries):
+        mu, cov = emu(q)
+        out[f"mu_{i}"], out[f"cov_{i}"] = mu, cov
+    model = ref_model(o)
+    ll, logdet, sqmah, flux, cov = parts(model)
+    out["lnl"] = np.array([ll, logdet, sqmah])
+    out["flux"] = flux
+    P = synth.walker_ball(o, B=4, seed=3)
+    lls = []
+    for p in P:
+        model.set_param_vector(p)
+        lls.append(model.log_likelihood())
+    out["batch_P"], out["batch_lnl"] = P, np.array(lls)
+    np.savez_compressed(os.path.join(OUT, "emulator_big.npz"), **out)
+    print("emulator_big.npz", ll)
+
+
 # -------------------------------------------------------------------------------- small models
 from gen_golden_cases import COV_ROWS, FULL_COV_CASES, SMALL_CASES, small_case_params  # noqa: E402
 
@@ -368,6 +393,8 @@ if __name__ == "__main__":
         gen_model_large([1024, 3000], {1024: 8, 3000: 2}, "large")
     if "cfg3" in only:
         gen_cfg3()
+    if "emulator_big" in only:
+        gen_emulator_big()
     if big:
         gen_model_large([4096], {4096: 8}, "cfg2")
         gen_model_large([16384], {}, "cfg5")
