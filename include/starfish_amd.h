@@ -301,6 +301,12 @@ int sf_band_logdet_gram_batch(const double* d_band, int n, int halfwidth, int ld
 int sf_profile_enable(int on);
 int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches, long* calls);
 
+/* Tuning / test aid (process-global): the batched Cholesky has two launch sequences -- the fused panel kernel
+ * (128-column panels; faster once the batch fills the chip) and the unfused one (256-column panels, separate
+ * panel-solve and diagonal-update launches; fewer sequential steps, faster for batches below ~24 matrices).
+ * mode -1 = choose by batch size (default), 0 = always fused, 1 = always unfused.  Same results to rounding. */
+int sf_debug_cholesky_sequence(int mode);
+
 /* Tuning aid: one wave spins for `wall_ticks_100mhz` ticks of the 100 MHz wall clock on `stream` and
  * writes {shader-clock ticks, wall ticks} to d_out2[2] -> sustained shader clock under load. */
 int sf_debug_clock_probe(long long* d_out2, long long wall_ticks_100mhz, void* stream);

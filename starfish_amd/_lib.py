@@ -137,6 +137,7 @@ SIGNATURES = {
         [_VP, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _VP, C.c_int, C.c_int, C.c_int64, _VP, _VP, _VP, _VP],
     ),
     "sf_debug_clock_probe": (C.c_int, [_VP, C.c_longlong, _VP]),
+    "sf_debug_cholesky_sequence": (C.c_int, [C.c_int]),
     "sf_profile_enable": (C.c_int, [C.c_int]),
     "sf_profile_read": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
 }

@@ -1491,6 +1491,9 @@ extern "C" int sf_logdet_sqmah_batch(const double* d_L, int n, int lda, int64_t 
                                   (hipStream_t)stream);
 }
 
+// Tuning / test aid: pin the launch sequence of the batched Cholesky (process-global).
+extern "C" int sf_debug_cholesky_sequence(int mode) { return sf_set_cholesky_sequence(mode); }
+
 // Tuning aid (not part of the Starfish surface): sustained shader clock while other streams are busy.
 extern "C" int sf_debug_clock_probe(long long* d_out2, long long wall_ticks_100mhz, void* stream) {
     return sf_launch_clock_probe(d_out2, wall_ticks_100mhz, (hipStream_t)stream);

@@ -9,6 +9,7 @@
 //   inside a panel, 64-column steps:  k_potrf_leaf (64x64 in LDS)  ->  k_trsm_leaf (row-per-lane
 //     substitution, x in registers, L^T broadcast from LDS)  ->  k_gemm_nt with K = 64.
 //   k_trsv_logdet: one forward substitution L z = R per matrix (sqmah = z.z) and 2 sum log L_ii.
+#include <atomic>
 #include <cstdlib>
 #include <vector>
 
@@ -1543,6 +1544,16 @@ static int sf_launch_potrf_v1(double* A, int n, int lda, int64_t stride, int bat
     return SF_OK;
 }
 
+static std::atomic<int> g_chol_sequence{-1};
+int sf_set_cholesky_sequence(int mode) {
+    if (mode < -1 || mode > 1) {
+        sf_set_error("cholesky sequence: -1 automatic, 0 fused panel kernel, 1 unfused");
+        return SF_EINVAL;
+    }
+    g_chol_sequence.store(mode);
+    return SF_OK;
+}
+
 // Factorisation with the fused panel kernel (default).  Panels of 128 columns; per panel k
 //   D(k)      k_diag_mfma on the updated diagonal tile (parked in the scratch T): L_kk, L_kk^-1, z_k
 //   top(k)    k_chol_panel for the slab of the NEXT diagonal tile (rows k1 .. k1+128): its updated tile goes to T
@@ -1696,7 +1707,12 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
 
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
                     double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
-    static const bool v1 = getenv("SF_CHOL_UNFUSED") != nullptr;  // tuning aid: the round-1 launch sequence
+    // The fused panel kernel (128-column panels) is the faster sequence once the batch fills the chip; small batches
+    // are bound by the number of sequential long-K steps, and the unfused sequence has half as many (256-column
+    // panels): measured at N = 4096, B = 16: 10.4 vs 11.2 ms; B = 32: 16.8 vs 16.9; B = 64: 29.5 vs 28.3; B = 128: 55.3 vs 51.
+    static const char* force = getenv("SF_CHOL_UNFUSED");  // tuning aid: "1" always unfused, "0" always fused
+    const int sel = g_chol_sequence.load();                 // sf_debug_cholesky_sequence(): tests drive both
+    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] != '0' : batch < 24);
     if (!ex) ex = sf_exec_thread_local();
     return v1 ? sf_launch_potrf_v1(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex)
               : sf_launch_potrf_v2(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);

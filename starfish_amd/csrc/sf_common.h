@@ -81,6 +81,7 @@ struct sf_gen_args {
 };
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
                     double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen = nullptr, sf_exec* ex = nullptr);
+int sf_set_cholesky_sequence(int mode);  // -1 automatic (by batch size), 0 fused panel kernel, 1 unfused
 int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batch, const double* z, int ldr,
                        double* logdet, double* sqmah, hipStream_t s);
 int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int batch,

@@ -48,7 +48,7 @@ def small():
 
 
 @pytest.mark.parametrize("name", list(G.SMALL_CASES))
-def test_small_model_cases_vs_reference(small, name):
+def test_small_model_cases_vs_reference(small, name, chol_sequence):
     o, oo, do = small
     g = load_golden("model_small.npz")
     p = small_params(o, name, g["factors"])
@@ -78,7 +78,7 @@ def test_small_model_cases_vs_reference(small, name):
     assert abs(ll["sqmah"][0] - ref[2]) <= 1e-8 * abs(ref[2])
 
 
-def test_batch_matches_oracle_and_reference_n1024():
+def test_batch_matches_oracle_and_reference_n1024(chol_sequence):
     g = load_golden("model_large.npz")
     o = synth.make_order(N=1024)
     oo = oracle_order(o)
@@ -103,7 +103,7 @@ def test_batch_matches_oracle_and_reference_n1024():
     np.testing.assert_array_equal(out2["lnl"], out["lnl"])
 
 
-def test_ragged_size_n3000_and_sampled_covariance():
+def test_ragged_size_n3000_and_sampled_covariance(chol_sequence):
     g = load_golden("model_large.npz")
     o = synth.make_order(N=3000)
     oo = oracle_order(o)
@@ -138,7 +138,7 @@ def test_out_of_grid_and_bad_vsini_are_flagged_not_fatal():
     assert out["lnl"][1] == -np.inf and out["lnl"][2] == -np.inf
 
 
-def test_wasp14_order_plumbing():
+def test_wasp14_order_plumbing(chol_sequence):
     """BASELINE config 1: bundled WASP14 order 23 (masked, N = 1932) against the reference value."""
     d = load_golden("wasp14_order23.npz")
     g = load_golden("model_wasp14.npz")
@@ -156,7 +156,7 @@ def test_wasp14_order_plumbing():
     assert close_lnl(O.log_likelihood(oo, p), g["lnl"][0])
 
 
-def test_cfg2_full_size_n4096_vs_reference():
+def test_cfg2_full_size_n4096_vs_reference(chol_sequence):
     """BASELINE config 2 at full size: the reference's own values (tools/gen_golden.py --big)."""
     g = load_golden("model_cfg2.npz")
     o = synth.make_order(N=4096)
@@ -185,7 +185,7 @@ def test_cfg2_full_size_n4096_vs_reference():
     np.testing.assert_allclose(fw["flux"][0], g["n4096_flux"], rtol=0, atol=1e-10)
 
 
-def test_cfg5_long_order_n16384_vs_reference():
+def test_cfg5_long_order_n16384_vs_reference(chol_sequence):
     """BASELINE config 5 (N = 16384, N_f = 32768: FFT through the global-memory path) against the value
     produced by the real reference."""
     g = load_golden("model_cfg5.npz")
@@ -224,7 +224,7 @@ def test_model_with_extinction_matches_oracle_unpinned():
 
 
 @pytest.mark.parametrize("N", [70, 200, 300, 520])
-def test_small_and_ragged_sizes_both_solvers(N):
+def test_small_and_ragged_sizes_both_solvers(N, chol_sequence):
     """Orders shorter than one panel, exactly one panel, and with a narrower last panel (padding to 64 for the
     dense factorisation, to 16 for the banded one): both solvers against the oracle."""
     o = synth.make_order(N=N, m=4, seed=3)

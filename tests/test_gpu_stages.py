@@ -86,8 +86,8 @@ def test_transform_argument_errors(gpu):
     np.testing.assert_allclose(T.instrumental_broaden(w, f, 0.0), f, atol=1e-14)
 
 
-@pytest.mark.parametrize("n,batch", [(64, 3), (256, 5), (1024, 2), (1088, 2)])
-def test_potrf_logdet_sqmah_random_spd(gpu, n, batch):
+@pytest.mark.parametrize("n,batch", [(64, 3), (256, 5), (1024, 2), (1088, 2), (1984, 3), (640, 40)])
+def test_potrf_logdet_sqmah_random_spd(gpu, chol_sequence, n, batch):
     import torch
     from starfish_amd import _device as D, _lib
 
@@ -122,7 +122,7 @@ def test_potrf_logdet_sqmah_random_spd(gpu, n, batch):
     np.testing.assert_allclose(Lgpu, np.linalg.cholesky(A[0, :, :n]), rtol=0, atol=1e-12)
 
 
-def test_potrf_reports_non_positive_pivot(gpu):
+def test_potrf_reports_non_positive_pivot(gpu, chol_sequence):
     import torch
     from starfish_amd import _device as D, _lib
 
