@@ -148,20 +148,6 @@ def cpu_baseline(order, plist, lnl_gpu, args):
 
 
 # ------------------------------------------------------------------------------------------- workloads
-def perturb_grid(order, rng_seed=7):
-    """A wavelength grid that is NOT log-uniform (pixel spacing modulated by +-5 %, like a real rectified order):
-    the likelihood path then evaluates K_global per entry instead of from the per-diagonal table."""
-    import numpy as np
-
-    w = order["wave"]
-    n = len(w)
-    step = np.diff(w) * (1 + 0.05 * np.sin(np.arange(n - 1) / 37.0))
-    order = dict(order)
-    order["wave"] = np.concatenate([[w[0]], w[0] + np.cumsum(step)])
-    order["flux"] = 1 + 0.1 * np.sin(order["wave"] / 7) + 0.01 * np.random.default_rng(rng_seed).standard_normal(n)
-    return order
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,7 +202,7 @@ def main():
     if n_orders == 1:
         order = synth.make_order(N=N)
         if args.grid == "perturbed":
-            order = perturb_grid(order)
+            order = synth.perturb_grid(order)
         model = synth.build_model(order)
         # weak: every rank its own B walkers (different seeds); strong: the config's B walkers split over the ranks
         P_all = synth.walker_ball(order, B=B, seed=1 + (rank if args.scaling == "weak" else 0))
@@ -243,7 +229,7 @@ def main():
     else:
         orders = synth.make_echelle(n_orders, N)
         if args.grid == "perturbed":
-            orders = [perturb_grid(o) for o in orders]
+            orders = [synth.perturb_grid(o) for o in orders]
         em = synth.build_echelle(orders)
         P_all = synth.shared_ball(orders[0], B=B, seed=1 + (rank if args.scaling == "weak" else 0))
         # order-major unit list (order o, walker w) -> this rank's contiguous slice keeps whole orders resident

@@ -238,3 +238,19 @@ def test_small_and_ragged_sizes_both_solvers(N, chol_sequence):
     for b, p in enumerate(plist):
         want = O.log_likelihood(oo, p)
         assert close_lnl(dense["lnl"][b], want) and close_lnl(auto["lnl"][b], want)
+
+
+def test_perturbed_grid_full_size_vs_oracle(chol_sequence):
+    """cfg 2 size on a NON log-uniform wavelength grid: the fill evaluates K_global entry by entry (no per-diagonal
+    table), through the product API, against the oracle."""
+    o = synth.perturb_grid(synth.make_order(N=4096))
+    rel = np.diff(o["wave"]) / o["wave"][:-1]
+    assert rel.max() / rel.min() > 1.05  # really not log-uniform
+    model = synth.build_model(o)
+    P = synth.walker_ball(o, B=2, seed=11)
+    got, info = model.log_likelihood_batch(P, return_info=True)
+    assert (info == 0).all()
+    oo = oracle_order(o)
+    for b in range(2):
+        want = O.log_likelihood(oo, synth.vector_to_oracle_params(P[b]))
+        assert close_lnl(got[b], want), (got[b], want)
