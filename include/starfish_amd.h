@@ -116,7 +116,9 @@ int sf_chebyshev_correct(const double* d_wave, int n, double wave_max, const dou
 int sf_extinct_ccm89(const double* d_wave, int n, const double* d_flux, int rows, double Av, double Rv,
                      double* d_out, void* stream);
 /* same with a choice of law: 0 = ccm89, 1 = odonnell94 (O'Donnell 1994: CCM89 with new optical/NIR
- * coefficients), 2 = calzetti00 (Calzetti et al. 2000, eq. 4).  All PARITY UNPINNED (literature formulas). */
+ * coefficients), 2 = calzetti00 (Calzetti et al. 2000, eq. 4), 3 = fitzpatrick99 (Fitzpatrick 1999: natural cubic
+ * spline through Rv-dependent anchors + FM90 ultraviolet curve), 4 = fm07 (Fitzpatrick & Massa 2007, Rv = 3.1 only).
+ * All PARITY UNPINNED (literature formulas).  Laws 3 and 4 synchronise the stream (a small table is uploaded). */
 int sf_extinct(const double* d_wave, int n, const double* d_flux, int rows, double Av, double Rv, int law,
                double* d_out, void* stream);
 

@@ -200,6 +200,48 @@ def calzetti00_a_lambda(wave, a_v, r_v=4.05):
     return a_v * k / r_v
 
 
+def _fm_uv(x, c1, c2, c3, c4, c5, x0, gamma, f99):
+    x = np.asarray(x, dtype=np.float64)
+    k = c1 + c2 * x + c3 * x**2 / ((x**2 - x0**2) ** 2 + x**2 * gamma**2)
+    y = np.where(x >= c5, x - c5, 0.0)
+    return k + (c4 * (0.5392 * y**2 + 0.05644 * y**3) if f99 else c4 * y**2)
+
+
+def fitzpatrick99_a_lambda(wave, a_v, r_v=3.1):
+    """Fitzpatrick (1999, PASP 111, 63): natural cubic spline in x = 1/lambda through Rv-dependent anchor points
+    (his FM_UNRED coding) below 1e4/2700 um^-1, FM90 ultraviolet curve above.  PARITY UNPINNED (see ccm89_a_lambda)."""
+    from scipy.interpolate import CubicSpline
+
+    c2 = -0.824 + 4.717 / r_v
+    c1 = 2.030 - 3.007 * c2
+    uv = (c1, c2, 3.23, 0.41, 5.9, 4.596, 0.99, True)
+    xk = np.array([0.0, 1e4 / 26500, 1e4 / 12200, 1e4 / 6000, 1e4 / 5470, 1e4 / 4670, 1e4 / 4110, 1e4 / 2700, 1e4 / 2600])
+    yk = np.array([
+        -r_v, 0.26469 * r_v / 3.1 - r_v, 0.82925 * r_v / 3.1 - r_v,
+        -4.22809e-01 + 1.00270 * r_v + 2.13572e-04 * r_v**2 - r_v,
+        -5.13540e-02 + 1.00216 * r_v - 7.35778e-05 * r_v**2 - r_v,
+        7.00127e-01 + 1.00184 * r_v - 3.32598e-05 * r_v**2 - r_v,
+        1.19456 + 1.01707 * r_v - 5.46959e-03 * r_v**2 + 7.97809e-04 * r_v**3 - 4.45636e-05 * r_v**4 - r_v,
+        *_fm_uv(xk[-2:], *uv),
+    ])
+    x = 1e4 / np.asarray(wave, dtype=np.float64)
+    k = np.where(x >= xk[-2], _fm_uv(x, *uv), CubicSpline(xk, yk, bc_type="natural")(np.minimum(x, xk[-1])))
+    return a_v * (1 + k / r_v)
+
+
+def fm07_a_lambda(wave, a_v):
+    """Fitzpatrick & Massa (2007, ApJ 663, 320) mean curve, Rv = 3.1.  PARITY UNPINNED."""
+    from scipy.interpolate import CubicSpline
+
+    r_v = 3.1
+    uv = (-0.175, 0.807, 2.991, 0.319, 6.097, 4.592, 0.922, False)
+    xk = np.array([0.0, 0.25, 0.50, 0.75, 1.0, 1e4 / 5530, 1e4 / 4000, 1e4 / 3300, 1e4 / 2700, 1e4 / 2600])
+    yk = np.concatenate([(-0.83 + 0.63 * r_v) * xk[:5] ** 1.84 - r_v, [0.0, 1.322, 2.055], _fm_uv(xk[-2:], *uv)])
+    x = 1e4 / np.asarray(wave, dtype=np.float64)
+    k = np.where(x >= xk[-2], _fm_uv(x, *uv), CubicSpline(xk, yk, bc_type="natural")(np.minimum(x, xk[-1])))
+    return a_v * (1 + k / r_v)
+
+
 def extinct_ccm89(wave, flux, a_v, r_v=3.1):
     """flux * 10**(-0.4 A_lambda)  (Starfish/transforms.py:205).  PARITY UNPINNED, see above."""
     return flux * 10 ** (-0.4 * ccm89_a_lambda(wave, a_v, r_v))

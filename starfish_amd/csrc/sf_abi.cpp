@@ -1452,13 +1452,89 @@ extern "C" int sf_extinct_ccm89(const double* d_wave, int n, const double* d_flu
     }
     return sf_launch_extinct_rows(d_wave, n, d_flux, rows, Av, Rv, 0, d_out, (hipStream_t)stream);
 }
+// Anchor points of the spline-based laws (k = E(lambda - V)/E(B - V) at x = 1/lambda [um^-1]) and the second
+// derivatives of the NATURAL cubic spline through them.  fitzpatrick99: Fitzpatrick (1999) section 5 / table 4 as
+// coded in his FM_UNRED: optical anchors as polynomials in Rv, infrared ones scaled by Rv/3.1, two ultraviolet
+// anchors from the FM90 curve with c2 = -0.824 + 4.717/Rv, c1 = 2.030 - 3.007 c2.  fm07: Fitzpatrick & Massa (2007)
+// mean curve, defined for Rv = 3.1 only.  PARITY UNPINNED (see the header).
+static int extinct_spline_table(int law, double Rv, std::vector<double>& tab) {
+    std::vector<double> xk, yk;
+    double c1, c2, c3, c4, c5, x0, gam, f99;
+    auto uv = [&](double x) {
+        const double x2 = x * x;
+        double k = c1 + c2 * x + c3 * x2 / ((x2 - x0 * x0) * (x2 - x0 * x0) + x2 * gam * gam);
+        if (x >= c5) {
+            const double y = x - c5;
+            k += f99 != 0.0 ? c4 * (0.5392 * y * y + 0.05644 * y * y * y) : c4 * y * y;
+        }
+        return k;
+    };
+    if (law == 3) {
+        x0 = 4.596, gam = 0.99, c3 = 3.23, c4 = 0.41, c5 = 5.9, f99 = 1.0;
+        c2 = -0.824 + 4.717 / Rv;
+        c1 = 2.030 - 3.007 * c2;
+        xk = {0.0, 1e4 / 26500.0, 1e4 / 12200.0, 1e4 / 6000.0, 1e4 / 5470.0, 1e4 / 4670.0, 1e4 / 4110.0, 1e4 / 2700.0, 1e4 / 2600.0};
+        const double r2 = Rv * Rv, r3 = r2 * Rv, r4 = r3 * Rv;
+        yk = {-Rv,
+              0.26469 * Rv / 3.1 - Rv,
+              0.82925 * Rv / 3.1 - Rv,
+              -4.22809e-01 + 1.00270 * Rv + 2.13572e-04 * r2 - Rv,
+              -5.13540e-02 + 1.00216 * Rv - 7.35778e-05 * r2 - Rv,
+              7.00127e-01 + 1.00184 * Rv - 3.32598e-05 * r2 - Rv,
+              1.19456 + 1.01707 * Rv - 5.46959e-03 * r2 + 7.97809e-04 * r3 - 4.45636e-05 * r4 - Rv,
+              uv(1e4 / 2700.0),
+              uv(1e4 / 2600.0)};
+    } else {
+        if (std::fabs(Rv - 3.1) > 1e-12) {
+            sf_set_error("fm07 is defined for Rv = 3.1 only");
+            return SF_EINVAL;
+        }
+        x0 = 4.592, gam = 0.922, c1 = -0.175, c2 = 0.807, c3 = 2.991, c4 = 0.319, c5 = 6.097, f99 = 0.0;
+        xk = {0.0, 0.25, 0.50, 0.75, 1.0, 1e4 / 5530.0, 1e4 / 4000.0, 1e4 / 3300.0, 1e4 / 2700.0, 1e4 / 2600.0};
+        yk.resize(xk.size());
+        for (int i = 0; i < 5; ++i) yk[i] = (-0.83 + 0.63 * Rv) * std::pow(xk[i], 1.84) - Rv;
+        yk[5] = 0.0;
+        yk[6] = 1.322;
+        yk[7] = 2.055;
+        yk[8] = uv(xk[8]);
+        yk[9] = uv(xk[9]);
+    }
+    const int nk = (int)xk.size();
+    // natural cubic spline: tridiagonal system for the second derivatives (y2[0] = y2[nk-1] = 0)
+    std::vector<double> y2(nk, 0.0), u(nk, 0.0);
+    for (int i = 1; i < nk - 1; ++i) {
+        const double sig = (xk[i] - xk[i - 1]) / (xk[i + 1] - xk[i - 1]);
+        const double pp = sig * y2[i - 1] + 2.0;
+        y2[i] = (sig - 1.0) / pp;
+        const double dd = (yk[i + 1] - yk[i]) / (xk[i + 1] - xk[i]) - (yk[i] - yk[i - 1]) / (xk[i] - xk[i - 1]);
+        u[i] = (6.0 * dd / (xk[i + 1] - xk[i - 1]) - sig * u[i - 1]) / pp;
+    }
+    for (int i = nk - 2; i >= 1; --i) y2[i] = y2[i] * y2[i + 1] + u[i];
+    tab = {(double)nk, c1, c2, c3, c4, c5, x0 * x0, gam * gam, f99};
+    tab.insert(tab.end(), xk.begin(), xk.end());
+    tab.insert(tab.end(), yk.begin(), yk.end());
+    tab.insert(tab.end(), y2.begin(), y2.end());
+    return SF_OK;
+}
 extern "C" int sf_extinct(const double* d_wave, int n, const double* d_flux, int rows, double Av, double Rv, int law,
                           double* d_out, void* stream) {
-    if (!d_wave || !d_flux || !d_out || n < 0 || rows <= 0 || !(Rv > 0.0) || law < 0 || law > 2) {
+    if (!d_wave || !d_flux || !d_out || n < 0 || rows <= 0 || !(Rv > 0.0) || law < 0 || law > 4) {
         sf_set_error("sf_extinct: bad argument");
         return SF_EINVAL;
     }
-    return sf_launch_extinct_rows(d_wave, n, d_flux, rows, Av, Rv, law, d_out, (hipStream_t)stream);
+    if (law <= 2) return sf_launch_extinct_rows(d_wave, n, d_flux, rows, Av, Rv, law, d_out, (hipStream_t)stream);
+    std::vector<double> tab;
+    int rc = extinct_spline_table(law, Rv, tab);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // the table rides in a small device buffer owned by this call (like sf_chebyshev_correct's coefficients)
+    double* dtab = nullptr;
+    SF_HIP(hipMalloc((void**)&dtab, sizeof(double) * tab.size()));
+    if (hipMemcpyAsync(dtab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, s) != hipSuccess) rc = SF_EHIP;
+    if (!rc) rc = sf_launch_extinct_spline_rows(d_wave, n, d_flux, rows, Av, Rv, dtab, d_out, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(dtab);
+    return rc;
 }
 
 extern "C" size_t sf_potrf_workspace_bytes(int n, int batch) {

@@ -80,6 +80,8 @@ int sf_launch_resid_y(const sf_resid_args& a, int B, hipStream_t s);
 
 int sf_launch_extinct_rows(const double* wave, int n, const double* flux, int rows, double Av, double Rv, int law,
                            double* out, hipStream_t s);  // law: 0 ccm89, 1 odonnell94, 2 calzetti00
+int sf_launch_extinct_spline_rows(const double* wave, int n, const double* flux, int rows, double Av, double Rv,
+                                  const double* d_table, double* out, hipStream_t s);  // law 3 / 4: table built by sf_extinct
 int sf_launch_cheb_rows(const double* wave, int n, double wave_max, const double* flux, int rows,
                         const double* d_coeffs, int ncoef, double* out, hipStream_t s);
 

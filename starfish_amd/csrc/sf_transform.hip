@@ -586,6 +586,43 @@ __global__ __launch_bounds__(256) void k_extinct_rows(const double* __restrict__
     for (int r = 0; r < rows; ++r) out[(int64_t)r * n + i] = flux[(int64_t)r * n + i] * mlt;
 }
 
+// Spline-based laws: Fitzpatrick (1999, PASP 111, 63) and Fitzpatrick & Massa (2007, ApJ 663, 320).  k(x) =
+// E(lambda - V)/E(B - V) is a natural cubic spline through a handful of anchor points in x = 1/lambda [um^-1] up to
+// 1e4/2700 and the Fitzpatrick-Massa ultraviolet parametrisation beyond; A_lambda = Av (1 + k / Rv).  The anchors,
+// their second derivatives (host: sf_extinct) and the UV constants arrive in `p`:
+//   p[0] = number of knots nk, p[1..7] = c1, c2, c3, c4, c5, x0^2, gamma^2, p[8] = 1 for the F99 far-UV term
+//   (0.5392 y^2 + 0.05644 y^3) / 0 for FM07's y^2, then xk[nk], yk[nk], y2[nk].   PARITY UNPINNED like the others.
+__global__ __launch_bounds__(256) void k_extinct_spline_rows(const double* __restrict__ wave, int n,
+                                                             const double* __restrict__ flux, int rows, double Av,
+                                                             double Rv, const double* __restrict__ p,
+                                                             double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int nk = (int)p[0];
+    const double* xk = p + 9;
+    const double* yk = xk + nk;
+    const double* y2 = yk + nk;
+    const double x = 1e4 / wave[i];
+    double k;
+    if (x >= xk[nk - 2]) {  // ultraviolet: lambda <= 2700 A (the last two knots are UV points themselves)
+        const double x2 = x * x;
+        const double d = x2 / ((x2 - p[6]) * (x2 - p[6]) + x2 * p[7]);
+        k = p[1] + p[2] * x + p[3] * d;
+        if (x >= p[5]) {
+            const double y = x - p[5];
+            k += p[8] != 0.0 ? p[4] * (0.5392 * y * y + 0.05644 * y * y * y) : p[4] * y * y;
+        }
+    } else {
+        int lo = 0;
+        while (lo + 2 < nk && x >= xk[lo + 1]) ++lo;
+        const double h = xk[lo + 1] - xk[lo];
+        const double a = (xk[lo + 1] - x) / h, b = (x - xk[lo]) / h;
+        k = a * yk[lo] + b * yk[lo + 1] + ((a * a * a - a) * y2[lo] + (b * b * b - b) * y2[lo + 1]) * (h * h) / 6.0;
+    }
+    const double mlt = pow(10.0, -0.4 * (Av * (1.0 + k / Rv)));
+    for (int r = 0; r < rows; ++r) out[(int64_t)r * n + i] = flux[(int64_t)r * n + i] * mlt;
+}
+
 // Generic resample (free function): out[r][q] = spline_r(xq[q]); coefficients coef[r][j] row-major.
 __global__ __launch_bounds__(256) void k_spline_eval(const double* __restrict__ coef, int rows, int ncoef,
                                                      const double* __restrict__ t,
@@ -1042,6 +1079,13 @@ int sf_launch_resid_y(const sf_resid_args& a, int B, hipStream_t s) {
 int sf_launch_extinct_rows(const double* wave, int n, const double* flux, int rows, double Av, double Rv, int law,
                            double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_extinct_rows, dim3((n + 255) / 256), dim3(256), 0, s, wave, n, flux, rows, Av, Rv, law, out);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+int sf_launch_extinct_spline_rows(const double* wave, int n, const double* flux, int rows, double Av, double Rv,
+                                  const double* d_table, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_extinct_spline_rows, dim3((n + 255) / 256), dim3(256), 0, s, wave, n, flux, rows, Av, Rv, d_table, out);
     SF_LAUNCH_CHECK();
     return SF_OK;
 }

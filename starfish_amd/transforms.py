@@ -92,15 +92,16 @@ def extinct(wave, flux, Av, Rv=3.1, law="ccm89"):
     which is not part of the reference tree and cannot be run here to generate vectors.  The default law
     ``ccm89`` is implemented from the published Cardelli, Clayton & Mathis (1989) formulas and checked
     against that paper's Table 3; ``odonnell94`` (O'Donnell 1994) and ``calzetti00`` (Calzetti et al. 2000,
-    eq. 4) likewise from the literature; the spline-based ``fitzpatrick99`` / ``fm07`` raise
-    ``NotImplementedError``."""
+    eq. 4) likewise from the literature, as are the spline-based ``fitzpatrick99`` (Fitzpatrick 1999) and ``fm07``
+    (Fitzpatrick & Massa 2007, defined for ``Rv = 3.1``: like the reference, which calls ``extinction.fm07(wave, Av)``
+    without ``Rv`` (transforms.py:199-200), the ``Rv`` argument is ignored for it)."""
     if law not in ["ccm89", "odonnell94", "calzetti00", "fitzpatrick99", "fm07"]:
         raise ValueError("Invalid extinction law given")
     if Rv <= 0:
         raise ValueError("Rv must be positive")
-    codes = {"ccm89": 0, "odonnell94": 1, "calzetti00": 2}
-    if law not in codes:
-        raise NotImplementedError(f"extinction law {law!r} is not provided (ccm89, odonnell94, calzetti00 are)")
+    codes = {"ccm89": 0, "odonnell94": 1, "calzetti00": 2, "fitzpatrick99": 3, "fm07": 4}
+    if law == "fm07":
+        Rv = 3.1  # transforms.py:199-200: the reference never passes Rv to fm07
     lib = _lib.require_gpu()
     wave = np.asarray(wave, dtype=np.float64)
     rows, one_d = _rows(flux)

@@ -176,8 +176,21 @@ def test_extinct_ccm89_unpinned_law(gpu):
         T.extinct(w, f, 1.0, law="nope")
     with pytest.raises(ValueError):
         T.extinct(w, f, 1.0, Rv=-1.0)
-    with pytest.raises(NotImplementedError):
-        T.extinct(w, f, 1.0, law="fm07")
+    # the spline-based laws (unpinned as well): restated from Fitzpatrick (1999) / Fitzpatrick & Massa (2007);
+    # fm07 ignores Rv like the reference's call (transforms.py:199-200)
+    np.testing.assert_allclose(T.extinct(w, f, 0.8, Rv=2.7, law="fitzpatrick99"),
+                               f * 10 ** (-0.4 * O.fitzpatrick99_a_lambda(w, 0.8, 2.7)), rtol=1e-12)
+    np.testing.assert_allclose(T.extinct(w, f, 1.1, law="fitzpatrick99"),
+                               f * 10 ** (-0.4 * O.fitzpatrick99_a_lambda(w, 1.1)), rtol=1e-12)
+    for rv in (3.1, 5.0):
+        np.testing.assert_allclose(T.extinct(w, f, 0.6, Rv=rv, law="fm07"), f * 10 ** (-0.4 * O.fm07_a_lambda(w, 0.6)),
+                                   rtol=1e-12)
+    for law in ("fitzpatrick99", "fm07"):
+        np.testing.assert_array_equal(T.extinct(w, f, 0.0, law=law), f)
+        v = T.extinct(np.array([5470.0, 5500.0]), np.ones(2), 1.0, law=law)
+        assert abs(-2.5 * np.log10(v[1]) - 1.0) < 3e-2  # A(V) ~ Av
+        a = -2.5 * np.log10(T.extinct(w, np.ones_like(w), 1.0, law=law))
+        assert np.all(np.diff(a[w > 2300]) < 0)  # monotonically falling redward of the 2175 A bump
     # the other two closed-form laws (also unpinned): restated formulas, identity at Av = 0, A(5500 A) = Av
     for law, alam in (("odonnell94", O.odonnell94_a_lambda), ("calzetti00", O.calzetti00_a_lambda)):
         np.testing.assert_array_equal(T.extinct(w, f, 0.0, law=law), f)

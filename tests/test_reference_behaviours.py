@@ -210,7 +210,7 @@ class TestChebyshevCorrection:
 
 @pytest.mark.gpu
 class TestExtinct:
-    laws = ["ccm89", "odonnell94", "calzetti00"]  # the closed-form laws; fitzpatrick99 / fm07 are not provided
+    laws = ["ccm89", "odonnell94", "calzetti00", "fitzpatrick99", "fm07"]
 
     @pytest.mark.parametrize("law", laws)
     @pytest.mark.parametrize("Av,Rv", [(0.4, 2), (0.6, 3.2), (1, 4), (1.2, 5)])
