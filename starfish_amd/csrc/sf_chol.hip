@@ -4,11 +4,17 @@
 // Starfish/models/spectrum_model.py:400-404 (dpotrf + dpotrs on the N x N covariance).
 //
 // Structure (one launch sequence serves the whole batch; the batch supplies the parallelism):
-//   outer LEFT-looking panels of SF_NB columns:   panel -= L[:, :k] L[k-block, :k]^T   (k_gemm_nt,
-//     v_mfma_f64_16x16x4_f64 tiles, the >90 % flops part, long K so C is read/written once)
-//   inside a panel, 64-column steps:  k_potrf_leaf (64x64 in LDS)  ->  k_trsm_leaf (row-per-lane
-//     substitution, x in registers, L^T broadcast from LDS)  ->  k_gemm_nt with K = 64.
-//   k_trsv_logdet: one forward substitution L z = R per matrix (sqmah = z.z) and 2 sum log L_ii.
+//   default (>= 24 matrices): LEFT-looking panels of 128 columns with the FUSED panel kernel k_chol_panel -- one
+//     workgroup per 128-row slab does the long-K update (v_mfma_f64_16x16x4_f64, > 80 % of the flops), the
+//     triangular solve against the explicit inverse of the diagonal tile, the in-place store of L, the forward
+//     substitution of the right-hand side and the rank-128 update of its own diagonal tile; k_diag_mfma factors
+//     the 128 x 128 diagonal tile (L_kk, L_kk^-1, z_k) on a side stream one panel ahead (lookahead); launches
+//     that cannot fill the chip are split along K (partial sums + deterministic reduce).  sf_launch_potrf_v2.
+//   small batches: the unfused sequence of round 1 (panels of SF_NB = 256 columns; k_gemm_nt long-K update into a
+//     panel scratch, k_diag_mfma on 256 x 256 blocks, separate panel-solve and diagonal-update launches): half as
+//     many sequential long-K steps.  sf_launch_potrf_v1.
+//   k_logdet_z: logdet = 2 sum log L_ii and sqmah = |z|^2 (z = L^-1 R is produced inside the factorisation);
+//   k_trsv_logdet: the stand-alone forward substitution of sf_logdet_sqmah_batch.
 #include <atomic>
 #include <cstdlib>
 #include <vector>
