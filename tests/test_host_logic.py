@@ -236,3 +236,35 @@ def test_every_status_code_of_the_header_has_a_python_message():
     for name, val in codes.items():
         assert val in D.INFO_MESSAGES, (name, val)
     assert D.INFO_BANDWIDTH == codes["SF_INFO_BANDWIDTH"]
+
+
+def test_echelle_from_orders_checks_labels_and_synth_helpers():
+    """Host-only: EchelleModel.from_orders refuses orders whose thawed labels differ; the multi-order synthetic
+    helpers keep the shared / per-order split the cfg 3 goldens were generated with."""
+    from starfish_amd import synth
+    from starfish_amd.models import EchelleModel
+
+    orders = synth.make_echelle(3, N=64, m=2)
+    assert orders[1]["wave"][0] == pytest.approx(5000.0 * 1.02)
+    models = [synth.build_model(o, freeze=("local_cov",)) for o in orders]
+    em = EchelleModel.from_orders(models)
+    assert len(em) == 3 and em.labels == synth.SHARED_LABELS
+    P = synth.shared_ball(orders[0], B=4)
+    assert P.shape == (4, len(synth.SHARED_LABELS))
+    p = synth.shared_to_oracle_params(orders[2], P[1])
+    assert p["local_cov"][0][0] == pytest.approx(orders[2]["wave"][64 // 3])  # the order's OWN local kernel
+    assert p["grid"] == list(P[1][-3:])
+    models[1].thaw("local_cov")
+    with pytest.raises(ValueError):
+        EchelleModel.from_orders(models)
+    with pytest.raises(ValueError):
+        EchelleModel.from_orders([])
+    # freeze / thaw bookkeeping of a group (table-driven implementation): members are listed once, thaw restores
+    m = models[0]
+    before = m.labels
+    m.thaw("local_cov")
+    assert "local_cov:0:mu" in m.labels and "local_cov" not in m.frozen
+    m.freeze("local_cov")
+    assert m.labels == before and m.frozen.count("local_cov:0:mu") == 1
+    with pytest.raises(ValueError):
+        m.thaw("global_cov")  # not frozen: list.remove raises, like the reference
