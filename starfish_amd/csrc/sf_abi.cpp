@@ -372,7 +372,7 @@ struct sf_ctx {
     int loguniform = 0;  // wave_i = wave_0 e^(i delta) to the rounding of the grid
     double dv = 0.0, wave_max = 0.0;
     DevBuf wave, flux, sigma, knots, spec, tw, Lf, Uf, rdiag, coef_static, inv_band;
-    DevBuf grid, variances, lengthscales, gmin, gmax, alpha, Linv;
+    DevBuf grid, variances, lengthscales, gmin, gmax, alpha, Linv;  // (Linv holds the TRANSPOSE of Lc^-1)
     sf_exec exec;        // side / auxiliary streams and the event pool of this context's launch sequences
     sf_exec exec_potrf;  // multi-order calls: the factorisation's own streams / events (exec pipelines the fills)
     ~sf_ctx() {
@@ -591,7 +591,13 @@ extern "C" sf_ctx* sf_ctx_create(const sf_order_desc* d, int device, int* err) {
         TRY(c->gmin.upload(gmin.data(), sizeof(double) * d->n_grid));
         TRY(c->gmax.upload(gmax.data(), sizeof(double) * d->n_grid));
         TRY(c->alpha.upload(alpha.data(), sizeof(double) * N));
-        TRY(c->Linv.upload(Linv.data(), sizeof(double) * (size_t)N * N));
+        {
+            // the batched product reads Linv by columns: store the transpose (row index fastest)
+            std::vector<double> LinvT((size_t)N * N);
+            for (int i = 0; i < N; ++i)
+                for (int j = 0; j < N; ++j) LinvT[(size_t)j * N + i] = Linv[(size_t)i * N + j];
+            TRY(c->Linv.upload(LinvT.data(), sizeof(double) * (size_t)N * N));
+        }
     }
 #undef TRY
     return c;
@@ -643,7 +649,7 @@ static size_t tilemap_bytes(const Layout& L) {  // per unit: one byte per 128 x 
 }
 static Layout layout_of(const sf_ctx* c) { return Layout{c->m, c->mpad, c->M, c->nf, c->rows, c->npad, c->lda}; }
 struct Work {
-    double *mu, *Lw, *zs, *scale, *logdet, *sqmah, *coef, *ybro, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf, *mult, *gtab;
+    double *mu, *Lw, *zs, *kv, *scale, *logdet, *sqmah, *coef, *ybro, *Xraw, *fraw, *resid, *Y, *C, *ztrsv, *ltbuf, *mult, *gtab;
     double2* fft;
     int *info_e, *info_c;
     unsigned char* tilemap;
@@ -662,6 +668,7 @@ static Work carve(const Layout& L, const sf_model_desc* mdl, int B, int Bt, void
     w.mu = k.take<double>(b * L.m);
     w.Lw = k.take<double>(b * L.m * L.m);
     w.zs = k.take<double>(b * L.m * L.M * L.m);
+    w.kv = k.take<double>(b * L.m * L.M);
     w.scale = k.take<double>(b);
     w.logdet = k.take<double>(b);
     w.sqmah = k.take<double>(b);
@@ -696,6 +703,7 @@ static Work slice(const Work& w, int u0) {
     s.mu += u * L.m;
     s.Lw += u * L.m * L.m;
     s.zs += u * L.m * L.M * L.m;
+    s.kv += u * L.m * L.M;
     s.scale += u;
     s.logdet += u;
     s.sqmah += u;
@@ -738,8 +746,9 @@ static sf_emu_args emu_args(sf_ctx* c, const sf_model_desc* mdl, const double* d
     e.gmin = c->gmin.as<double>();
     e.gmax = c->gmax.as<double>();
     e.alpha = c->alpha.as<double>();
-    e.Linv = c->Linv.as<double>();
+    e.LinvT = c->Linv.as<double>();
     e.zscratch = w.zs;
+    e.kbuf = w.kv;
     e.mu = d_mu;
     e.cov = d_cov;
     e.Lw = d_Lw;

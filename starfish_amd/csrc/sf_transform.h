@@ -95,8 +95,9 @@ struct sf_emu_args {
     const double* gmin;          // [P]
     const double* gmax;          // [P]
     const double* alpha;         // [mM]   v11^-1 w_hat
-    const double* Linv;          // [mM][mM] inverse of the lower Cholesky factor of v11
+    const double* LinvT;         // [mM][mM] TRANSPOSE of the inverse of the lower Cholesky factor of v11
     double* zscratch;            // [B][mM][m]
+    double* kbuf;                // [B][mM] v12 blocks of every walker
     double* mu;                  // [B][m]
     double* cov;                 // [B][m][m] or NULL
     double* Lw;                  // [B][m][m] or NULL

@@ -3,7 +3,7 @@ Query side of the Bayesian spectral emulator (reference: Starfish/emulator/emula
 
 Kept: the constructor and its attributes, ``__call__`` (GP conditional mean / covariance of the PCA
 weights), ``bulk_fluxes``, ``norm_factor``, hyper-parameter accessors, ``load`` / ``save``.
-``__call__`` runs in the ``k_emulator`` HIP kernel through ``sf_emulator_query_batch``; the constant
+``__call__`` runs in the ``k_emu_*`` HIP kernels through ``sf_emulator_query_batch``; the constant
 ``v11`` is factored once per hyper-parameter set instead of on every call (emulator.py:387-388).
 ``log_likelihood`` / ``train`` reuse the batched Cholesky kernels.
 Out of scope (one-time offline set-up): ``from_grid`` (PCA), plotting.

@@ -1,6 +1,6 @@
 """RBF kernels of the emulator GP (reference: Starfish/emulator/kernels.py).  These host versions
 only build the constant ``v11`` at construction / hyper-parameter changes; the per-step ``v12``
-blocks are evaluated inside the ``k_emulator`` HIP kernel."""
+blocks are evaluated inside the ``k_emu_prep`` HIP kernel."""
 import numpy as np
 
 

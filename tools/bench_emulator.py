@@ -1,4 +1,4 @@
-"""Time the emulator query kernel (k_emulator) at a realistic library size: m = 4, M = 330 (m M = 1320).
+"""Time the emulator query kernels (k_emu_prep, k_emu_z, k_emu_post) at a realistic library size: m = 4, M = 330 (m M = 1320).
     python tools/bench_emulator.py [B]"""
 import os
 import sys
