@@ -268,3 +268,21 @@ def test_echelle_from_orders_checks_labels_and_synth_helpers():
     assert m.labels == before and m.frozen.count("local_cov:0:mu") == 1
     with pytest.raises(ValueError):
         m.thaw("global_cov")  # not frozen: list.remove raises, like the reference
+
+
+def test_bench_builds_through_the_product_and_keeps_the_oracle_in_the_baseline_leg():
+    """bench.py must not depend on the test tree, and may touch the oracle only inside the cpu_baseline functions."""
+    import ast
+
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "gpu_helpers" not in src and '"tests"' not in src
+    tree = ast.parse(src)
+    allowed = {"_cpu_pool_worker", "cpu_baseline"}
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+        name = getattr(fn, "name", "<module>")
+        body = fn.body if isinstance(fn, ast.Module) else fn.body
+        for node in body if isinstance(fn, ast.Module) else ast.walk(fn):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "oracle":
+                assert name in allowed, f"oracle imported in {name}"
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                assert name in allowed, f"oracle imported in {name}"
