@@ -1005,30 +1005,48 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             Ap[p] = Cb + (int64_t)(row0 + min(lr + 64 * p, rows_here - 1)) * g.lda + lc;
             Bp[p] = Cb + (int64_t)(k0 + min(lr + 64 * p, pw - 1)) * g.lda + lc;
         }
-        double2 ra[2], rb[2];
-        auto gload = [&](int kt) {
+        // Operand staging: DIRECT global -> LDS loads (global_load_lds_dwordx4: no staging registers, no ds_write
+        // pass).  A wave instruction deposits 64 consecutive 16-byte granules = 8 unpadded rows of a 16-double K slab;
+        // bank conflicts are avoided by an XOR swizzle of the granule index with (row >> 1) & 7, applied on the SOURCE
+        // address here and on the fragment reads below (the LDS image itself is lane-linear).
+        const int grow = lane >> 3, gpos = lane & 7;  // row within the 8-row group, granule slot within the row
+        const double* Ag[2];
+        const double* Bg[2];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                ra[p] = *(const double2*)(Ap[p] + kt * GK);
-                rb[p] = *(const double2*)(Bp[p] + kt * GK);
+        for (int q = 0; q < 2; ++q) {
+            const int row = 16 * w + 8 * q + grow;
+            const int c = gpos ^ ((row >> 1) & 7);
+            Ag[q] = Cb + (int64_t)(row0 + min(row, rows_here - 1)) * g.lda + 2 * c;
+            Bg[q] = Cb + (int64_t)(k0 + min(row, pw - 1)) * g.lda + 2 * c;
+        }
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+        double* A2 = sm;                // [2][128 x 16]
+        double* B2 = sm + 2 * GT * GK;  // [2][128 x 16]
+        // (inline asm: hipcc drains vmcnt(0) before the next LDS read of ANY buffer when it sees the builtin in
+        // flight; the loads are therefore hidden from it and waited for by hand right before the barrier)
+        const unsigned ldsA = (unsigned)(size_t)(lds_ptr)A2, ldsB = (unsigned)(size_t)(lds_ptr)B2;
+        auto glds16 = [&](const double* src, unsigned lds_dst) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "s"(lds_dst)
+                         : "memory");
+        };
+        auto gload = [&](int kt, int buf) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned off = (unsigned)(buf * GT * GK + (16 * w + 8 * q) * GK) * 8u;
+                glds16(Ag[q] + kt * GK, ldsA + off);
+                glds16(Bg[q] + kt * GK, ldsB + off);
             }
         };
-        auto lstore = [&](int buf) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                double* pa = &As[buf][(lr + 64 * p) * GLD + lc];
-                double* pb = &Bs[buf][(lr + 64 * p) * GLD + lc];
-                pa[0] = ra[p].x;
-                pa[1] = ra[p].y;
-                pb[0] = rb[p].x;
-                pb[1] = rb[p].y;
-            }
-        };
+        auto gwait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         const int nk_all = (g.skip & 4) ? 0 : k0 / GK;
         const int kbeg = MODE == 1 ? min(sp * g.kchunk, nk_all) : 0;
         const int kend = MODE == 1 ? min(kbeg + g.kchunk, nk_all) : (MODE == 2 ? 0 : nk_all);
         const int nk = kend - kbeg;
-        if (nk > 0) gload(kbeg);
+        if (nk > 0) gload(kbeg, 0);
 
         bool generate = false;
         if (g.tilemap) generate = !g.tilemap[(int64_t)b * g.nt128 * g.nt128 + (row0 / GT) * g.nt128 + k0 / GT];
@@ -1091,32 +1109,52 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
                     }
                 }
         }
-        if (nk > 0) lstore(0);
+        gwait();
         __syncthreads();
+        // (the accumulators come from compiler-counted loads: consume them here, so that hipcc places its own
+        // vmcnt(0) for them BEFORE the loop and not inside it, where it would also drain the hand-counted prefetch)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(acc[mi][ni][r]));
+        // fragment reads: lane (l15, lq) takes the two granules 2 lq, 2 lq + 1 of its row = the four consecutive
+        // k = 4 lq .. 4 lq + 3; MFMA j of a slab uses element j of every lane, i.e. slice lq of instruction j stands
+        // for k = 4 lq + j -- in both operands (K is a summation index)
         auto compute = [&](int cur) {
-            const double* Ab = &As[cur][(wm * (16 * TM) + l15) * GLD + lq];
-            const double* Bb = &Bs[cur][(wn * (16 * TN) + l15) * GLD + lq];
+            const double* Ab = A2 + cur * GT * GK;
+            const double* Bb = B2 + cur * GT * GK;
 #pragma unroll
-            for (int ks = 0; ks < GK / 4; ++ks) {
-                double a[TM], bb[TN];
+            for (int h = 0; h < 2; ++h) {
+                double2 a[TM], bb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = Ab[i * 16 * GLD + ks * 4];
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * (16 * TM) + i * 16 + l15;
+                    a[i] = *(const double2*)(Ab + row * GK + 2 * ((2 * lq + h) ^ ((row >> 1) & 7)));
+                }
 #pragma unroll
-                for (int i = 0; i < TN; ++i) bb[i] = Bb[i * 16 * GLD + ks * 4];
+                for (int i = 0; i < TN; ++i) {
+                    const int row = wn * (16 * TN) + i * 16 + l15;
+                    bb[i] = *(const double2*)(Bb + row * GK + 2 * ((2 * lq + h) ^ ((row >> 1) & 7)));
+                }
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[ni], acc[mi][ni], 0, 0, 1);  // neg:[1,0,0]
+                    for (int ni = 0; ni < TN; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi].x, bb[ni].x, acc[mi][ni], 0, 0, 1);  // neg:[1,0,0]
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi].y, bb[ni].y, acc[mi][ni], 0, 0, 1);
+                    }
             }
         };
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            gload(kbeg + kt + 1);
+            gload(kbeg + kt + 1, (kt & 1) ^ 1);
             compute(kt & 1);
-            lstore((kt & 1) ^ 1);
+            gwait();
             __syncthreads();
         }
         if (nk > 0) compute((nk - 1) & 1);
+        __syncthreads();  // the epilogue re-uses the LDS with its own layouts
         if (MODE == 1) {
             double* P = g.part + ((int64_t)tile * g.ksplit + sp) * (GT * GT);
 #pragma unroll
