@@ -949,6 +949,12 @@ struct sf_panel_args {
     int ldy, mpad, nt128;
 };
 
+// granule swizzle of the main loop's LDS image (see k_chol_panel)
+__device__ __forceinline__ int sf_swz(int row) {
+    const int t = (row >> 1) & 7;
+    return t ^ ((((t >> 1) ^ (t >> 2)) & 1) << 1);
+}
+
 // one 16-wide K block of the triangular solve for the 16-column blocks ni >= NI_LO of a wave
 template <int NI_LO>
 __device__ __forceinline__ void sf_solve_step(sf_d4 (&acc)[2][4], const double* Ab, const double* Bb) {
@@ -1007,15 +1013,18 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         }
         // Operand staging: DIRECT global -> LDS loads (global_load_lds_dwordx4: no staging registers, no ds_write
         // pass).  A wave instruction deposits 64 consecutive 16-byte granules = 8 unpadded rows of a 16-double K slab;
-        // bank conflicts are avoided by an XOR swizzle of the granule index with (row >> 1) & 7, applied on the SOURCE
-        // address here and on the fragment reads below (the LDS image itself is lane-linear).
+        // bank conflicts are avoided by an XOR swizzle of the granule index with sf_swz(row), applied on the SOURCE
+        // address here and on the fragment reads below (the LDS image itself is lane-linear).  The swizzle is made
+        // for the lane groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: each holds all 16 rows of a
+        // fragment once, rows 0-3 / 12-15 with one granule column and rows 4-11 with the column two further): with
+        // t = (row >> 1) & 7, rows with t in {2,3,4,5} get t ^ 2, the others t -- 16 distinct 16-byte bank slots.
         const int grow = lane >> 3, gpos = lane & 7;  // row within the 8-row group, granule slot within the row
         const double* Ag[2];
         const double* Bg[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int row = 16 * w + 8 * q + grow;
-            const int c = gpos ^ ((row >> 1) & 7);
+            const int c = gpos ^ sf_swz(row);
             Ag[q] = Cb + (int64_t)(row0 + min(row, rows_here - 1)) * g.lda + 2 * c;
             Bg[q] = Cb + (int64_t)(k0 + min(row, pw - 1)) * g.lda + 2 * c;
         }
@@ -1131,12 +1140,12 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = wm * (16 * TM) + i * 16 + l15;
-                    a[i] = *(const double2*)(Ab + row * GK + 2 * ((2 * lq + h) ^ ((row >> 1) & 7)));
+                    a[i] = *(const double2*)(Ab + row * GK + 2 * ((2 * lq + h) ^ sf_swz(row)));
                 }
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     const int row = wn * (16 * TN) + i * 16 + l15;
-                    bb[i] = *(const double2*)(Bb + row * GK + 2 * ((2 * lq + h) ^ ((row >> 1) & 7)));
+                    bb[i] = *(const double2*)(Bb + row * GK + 2 * ((2 * lq + h) ^ sf_swz(row)));
                 }
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
