@@ -305,7 +305,7 @@ int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches
 
 /* Tuning / test aid (process-global): the batched Cholesky has two launch sequences -- the fused panel kernel
  * (128-column panels; faster once the batch fills the chip) and the unfused one (256-column panels, separate
- * panel-solve and diagonal-update launches; fewer sequential steps, faster for batches below ~24 matrices).
+ * panel-solve and diagonal-update launches; fewer sequential steps, faster for batches below ~28 matrices).
  * mode -1 = choose by batch size (default), 0 = always fused, 1 = always unfused.  Same results to rounding. */
 int sf_debug_cholesky_sequence(int mode);
 

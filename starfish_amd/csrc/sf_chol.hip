@@ -1768,10 +1768,11 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
                     double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
     // The fused panel kernel (128-column panels) is the faster sequence once the batch fills the chip; small batches
     // are bound by the number of sequential long-K steps, and the unfused sequence has half as many (256-column
-    // panels): measured at N = 4096, B = 16: 10.4 vs 11.2 ms; B = 32: 16.8 vs 16.9; B = 64: 29.5 vs 28.3; B = 128: 55.3 vs 51.
+    // panels): measured at N = 4096, B = 16: 10.3 vs 11.2 ms; B = 24: 13.3 vs 13.7; B = 32: 16.6 vs 16.3; B = 64: 29.5 vs 28.3;
+    // B = 128: 55.3 vs 50.4.
     static const char* force = getenv("SF_CHOL_UNFUSED");  // tuning aid: "1" always unfused, "0" always fused
     const int sel = g_chol_sequence.load();                 // sf_debug_cholesky_sequence(): tests drive both
-    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] != '0' : batch < 24);
+    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] != '0' : batch < 28);
     if (!ex) ex = sf_exec_thread_local();
     return v1 ? sf_launch_potrf_v1(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex)
               : sf_launch_potrf_v2(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
