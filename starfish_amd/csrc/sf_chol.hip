@@ -4,7 +4,7 @@
 // Starfish/models/spectrum_model.py:400-404 (dpotrf + dpotrs on the N x N covariance).
 //
 // Structure (one launch sequence serves the whole batch; the batch supplies the parallelism):
-//   default (>= 24 matrices): LEFT-looking panels of 128 columns with the FUSED panel kernel k_chol_panel -- one
+//   default (>= 28 matrices): LEFT-looking panels of 128 columns with the FUSED panel kernel k_chol_panel -- one
 //     workgroup per 128-row slab does the long-K update (v_mfma_f64_16x16x4_f64, > 80 % of the flops), the
 //     triangular solve against the explicit inverse of the diagonal tile, the in-place store of L, the forward
 //     substitution of the right-hand side and the rank-128 update of its own diagonal tile; k_diag_mfma factors
