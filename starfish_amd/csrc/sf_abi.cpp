@@ -1060,13 +1060,14 @@ static int multi_layout(const sf_segment* segs, int nseg, const sf_model_desc* m
     *bmax = bm;
     return SF_OK;
 }
-// chunks of a multi-order call: whole segments, at least this many units (enough matrices to keep the launches of
-// a factorisation full); two factorisations run at a time
-static int multi_min_units(int U) {
-    static const int nchunks = getenv("SF_MULTI_CHUNKS") ? std::max(1, atoi(getenv("SF_MULTI_CHUNKS"))) : 2;  // tuning aid (1, 2, 3, 4 chunks: 283.1, 282.1, 282.7, 283.9 ms at cfg 3)
-    return std::max(256, (U + nchunks - 1) / nchunks);
+// Chunks of a multi-order call (whole segments): a SMALL first chunk (at least 256 units: enough matrices to keep a
+// factorisation's launches full) and the rest as the second -- only the first chunk's fills are exposed, the others
+// run behind the first factorisation.  (Equal chunks: 1, 2, 3, 4 of them gave 283.1, 282.1, 282.7, 283.9 ms at cfg 3.)
+static int multi_first_units(int U) {
+    static const int first = getenv("SF_MULTI_FIRST") ? std::max(1, atoi(getenv("SF_MULTI_FIRST"))) : 256;  // tuning aid
+    return std::min(U, first);
 }
-static int multi_chunk_cap(int U, int bmax) { return std::min(U, multi_min_units(U) + bmax); }
+static int multi_chunk_cap(int U, int bmax) { return std::min(U, std::max(U - multi_first_units(U), multi_first_units(U) + bmax)); }
 extern "C" size_t sf_multi_workspace_bytes(const sf_segment* segs, int nseg, const sf_model_desc* mdl) {
     Layout L;
     int U = 0, bmax = 0;
@@ -1098,14 +1099,13 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
     const int nt128 = (L.npad + 127) / 128;
     // Pipeline: the per-order transform chains and fills (many small launches, a few per cent of the step) run on
     // the context's auxiliary stream one chunk of orders ahead of the factorisation on the caller's stream, so all
-    // but the first chunk's are hidden behind the Cholesky of the previous chunk.  Chunks are whole segments of
-    // at least `min_units` units (enough matrices to keep the factorisation's launches full).
+    // but the first chunk's are hidden behind the Cholesky of the previous chunk (see multi_first_units).
     sf_exec* ex = &c0->exec;
     rc = sf_exec_prepare(ex);
     if (rc) return rc;
     static const bool no_pipe = getenv("SF_MULTI_NO_PIPELINE") != nullptr;  // tuning aid
     hipStream_t sp = no_pipe ? s : ex->aux;
-    const int min_units = multi_min_units(U);
+    const int first_units = multi_first_units(U);
     if (sp != s) {
         SF_HIP(hipEventRecord(ex->fork, s));
         SF_HIP(hipStreamWaitEvent(sp, ex->fork, 0));
@@ -1141,7 +1141,7 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
             if (rc) return rc;
         }
         u0 += B;
-        if (u0 - cu0 >= min_units || i == nseg - 1) {
+        if ((chunks.empty() && u0 - cu0 >= first_units) || i == nseg - 1) {
             Chunk ch{cu0, u0 - cu0, nullptr};
             if (sp != s) {
                 rc = sf_exec_event(ex, &ch.filled);

@@ -1029,7 +1029,6 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             Bg[q] = Cb + (int64_t)(k0 + min(row, pw - 1)) * g.lda + 2 * c;
         }
         typedef __attribute__((address_space(3))) void* lds_ptr;
-        typedef const __attribute__((address_space(1))) void* glb_ptr;
         double* A2 = sm;                // [2][128 x 16]
         double* B2 = sm + 2 * GT * GK;  // [2][128 x 16]
         // (inline asm: hipcc drains vmcnt(0) before the next LDS read of ANY buffer when it sees the builtin in
