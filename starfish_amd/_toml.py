@@ -1,5 +1,7 @@
 """Minimal TOML writer (+ tomli-based reader) for SpectrumModel.save / load
 (reference format: Starfish/models/spectrum_model.py:592-633; the `toml` package is not available)."""
+import datetime as _dt
+
 import numpy as np
 
 
@@ -18,6 +20,8 @@ def _scalar(v):
         return r if any(c in r for c in ".en") else r + ".0"
     if isinstance(v, str):
         return '"' + v.replace("\\", "\\\\").replace('"', '\\"') + '"'
+    if isinstance(v, (_dt.datetime, _dt.date, _dt.time)):
+        return v.isoformat()  # RFC 3339, a native TOML value (metadata commonly carries a date)
     raise TypeError(f"cannot write {type(v).__name__} to TOML")
 
 

@@ -9,6 +9,7 @@ the HIP kernels behind ``include/starfish_amd.h``; this file only keeps the para
 (FlatterDict store, labels, freeze / thaw, caches) and packs parameter rows for the C-ABI.
 """
 import logging
+import zlib
 from collections import deque
 
 import numpy as np
@@ -69,6 +70,7 @@ class SpectrumModel:
         self._bulk_fluxes = None  # resampled lazily on the device (spectrum_model.py:154-156)
         self._dev = None
         self._dev_v11 = None
+        self._dev_data = None
 
         self.residuals = deque(maxlen=max_deque_len)
 
@@ -102,8 +104,13 @@ class SpectrumModel:
 
     def _device(self):
         emu = self.emulator
-        stale = self._dev is None or self._dev_v11 is not emu.v11
+        # the observation lives in HBM; the reference reads self.data on every evaluation
+        # (spectrum_model.py:365-377), so a replaced or edited flux / sigma must reach the device copy
+        d = self.data
+        key = tuple(zlib.crc32(np.ascontiguousarray(a)) for a in (d.wave, d.flux, d.sigma))
+        stale = self._dev is None or self._dev_v11 is not emu.v11 or key != self._dev_data
         if stale:
+            self._dev_data = key
             self._dev = D.DeviceOrder(
                 self.data.wave, self.data.flux, self.data.sigma, self.min_dv_wave, self.bulk_fluxes,
                 emu.grid_points, emu.variances, emu.lengthscales, emu.v11, emu.w_hat,
