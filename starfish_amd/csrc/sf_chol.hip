@@ -1130,9 +1130,14 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         // fragment reads: lane (l15, lq) takes the two granules 2 lq, 2 lq + 1 of its row = the four consecutive
         // k = 4 lq .. 4 lq + 3; MFMA j of a slab uses element j of every lane, i.e. slice lq of instruction j stands
         // for k = 4 lq + j -- in both operands (K is a summation index)
+        // (a wave whose 32 rows lie beyond the matrix -- the last slab of an order that is not a multiple of 128,
+        // e.g. 3008 = 23.5 slabs -- leaves the matrix core to the other waves: its tile is never stored.  cfg 3:
+        // 5 % of the long-K MFMA work, 5650 -> 5940 order-evals/s)
+        const bool wave_live = wm * (16 * TM) < rows_here;
         auto compute = [&](int cur) {
             const double* Ab = A2 + cur * GT * GK;
             const double* Bb = B2 + cur * GT * GK;
+            if (!wave_live) return;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 double2 a[TM], bb[TN];
@@ -1229,7 +1234,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             // branch around a straight-line body; inside it the zero blocks of W are multiplied through, which
             // leaves the not-yet-dumped T blocks and the finished sums bit-for-bit unchanged.  Skipping block by
             // block -- a switch over four straight-line bodies -- makes hipcc spill ~250 VGPRs: measured, not kept)
-            if (sb <= wn * TN + (TN - 1)) {
+            if (sb <= wn * TN + (TN - 1) && wave_live) {
                 const double* Ab = &Ach[(wm * (16 * TM) + l15) * CLD + (sb & 1) * 16 + lq];
                 const double* Bb = &Bs[buf][(wn * (16 * TN) + l15) * GLD + lq];
                 sf_solve_step<0>(acc, Ab, Bb);
