@@ -947,6 +947,10 @@ struct sf_panel_args {
     const unsigned char* tilemap;
     int64_t sY;
     int ldy, mpad, nt128;
+    // bordered band matrices (sf_launch_potrf_band): rows < nband have no entries further than kband columns left of
+    // the diagonal, so the K loop of a slab starts at its first non-zero column; rows >= nband (the border: dense
+    // rows that ride along) form one extra slab at xrow0, the last of the launch.  All 0 for dense matrices.
+    int kband, nband, xrow0;
 };
 
 // granule swizzle of the main loop's LDS image (see k_chol_panel)
@@ -987,8 +991,8 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
     const int sp = MODE == 1 ? id - tile * g.ksplit : 0;
     const int b = tile / g.nslab;
     const int sl = tile - b * g.nslab;
-    const int row0 = g.row0 + sl * g.slab_step * GT;
-    const int rows_here = min(GT, g.n - row0);
+    const int row0 = (g.xrow0 && sl == g.nslab - 1) ? g.xrow0 : g.row0 + sl * g.slab_step * GT;
+    const int rows_here = min(GT, ((g.nband && row0 < g.nband) ? g.nband : g.n) - row0);
     const int pw = g.pw, k0 = g.k0;
 
     const int tid = threadIdx.x;
@@ -1051,8 +1055,11 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         };
         auto gwait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         const int nk_all = (g.skip & 4) ? 0 : k0 / GK;
-        const int kbeg = MODE == 1 ? min(sp * g.kchunk, nk_all) : 0;
-        const int kend = MODE == 1 ? min(kbeg + g.kchunk, nk_all) : (MODE == 2 ? 0 : nk_all);
+        // band: the K loop starts at the first column where both operands can be non-zero (a band slab's own rows;
+        // for the dense border rows the panel's rows decide -- what lies left of that was never even written)
+        const int klo = g.kband ? min(max((row0 < g.nband ? row0 : k0) - g.kband, 0) / GK, nk_all) : 0;
+        const int kbeg = MODE == 1 ? min(klo + sp * g.kchunk, nk_all) : klo;
+        const int kend = MODE == 1 ? min(kbeg + g.kchunk, nk_all) : (MODE == 2 ? kbeg : nk_all);
         const int nk = kend - kbeg;
         if (nk > 0) gload(kbeg, 0);
 
@@ -1347,8 +1354,9 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             __syncthreads();
         }
         if (nk2 > 0) compute2((nk2 - 1) & 1);
-        double* So = g.Sout ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
-        const int ldo = g.Sout ? g.ldS : g.lda;
+        const bool parked = g.Sout && sl == 0;  // (only the first slab of a launch is the next diagonal tile)
+        double* So = parked ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
+        const int ldo = parked ? g.ldS : g.lda;
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             if (q >= nstore) continue;
@@ -1765,6 +1773,155 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
     }
     for (int g = 1; g < G; ++g)
         if (e_rest[g]) SF_HIP(hipStreamWaitEvent(s, e_rest[g], 0));
+    return SF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bordered band matrices on the fused panel kernel (the structure-exploiting solver for half-widths beyond the
+// LDS window of k_band_forms):
+//
+//        [ Bd   .  ]      Bd: nband x nband, zero further than `halfwidth` from the diagonal (128 x 128 tiles of a
+//    A = [         ]          dense-strided array; only the tiles that meet the band are ever touched)
+//        [ R    G  ]      R:  the 1 + m right-hand sides as 64 extra ROWS,  G = 0
+//
+// Left-looking panels exactly as in sf_launch_potrf_v2, but rest(k) covers only the slabs that meet the band plus the
+// border slab, and every slab's K loop starts at its first non-zero column: O(n W^2) flops on kernels that run at
+// the dense path's rate, spread over the whole chip (k_band_wide keeps one matrix on one CU and streams its
+// operands from L2).  The border rows come out as Z = R L^-T, their diagonal tile as -Z Z^T: the Gram matrix the
+// Woodbury step needs; L_band's diagonal gives logdet(Bd).  The diagonal tile of the border is never factorised.
+__global__ __launch_bounds__(256) void k_band_to_tiles(const double* __restrict__ band, int64_t sband, int ldb, int halfwidth,
+                                                       int n, int nband, int wt, double* __restrict__ A, int64_t sA, int lda) {
+    const int b = blockIdx.z, ti = blockIdx.y, tj = ti - (int)blockIdx.x;  // tile (ti, tj), tj = ti - 0 .. ti - wt
+    if (tj < 0) return;
+    const double* bd = band + (int64_t)b * sband;
+    double* Ab = A + (int64_t)b * sA;
+    for (int e = threadIdx.x; e < GT * GT; e += 256) {
+        const int I = ti * GT + (e >> 7), J = tj * GT + (e & 127);
+        if (I >= nband || J >= nband) continue;
+        const int hi = max(I, J), d = hi - min(I, J);
+        double v = d == 0 ? 1.0 : 0.0;  // identity padding beyond the data
+        if (hi < n) v = d <= halfwidth ? bd[(int64_t)hi * ldb + d] : 0.0;
+        Ab[(int64_t)I * lda + J] = v;
+    }
+}
+// border rows: row 0 <- rhs0 (the residual), rows 1 .. nrhs-1 <- rhs rows, everything else (and the border's own
+// diagonal tile) zero
+__global__ __launch_bounds__(256) void k_band_border_rows(const double* __restrict__ rhs0, int64_t srhs0, const double* __restrict__ rhs,
+                                                          int64_t srhs, int ldr, int nrhs, int n, int nband, double* __restrict__ A,
+                                                          int64_t sA, int lda) {
+    const int b = blockIdx.z, r = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= nband + 64) return;
+    double v = 0.0;
+    if (r < nrhs && col < n) v = r == 0 ? rhs0[(int64_t)b * srhs0 + col] : rhs[(int64_t)b * srhs + (int64_t)(r - 1) * ldr + col];
+    A[(int64_t)b * sA + (int64_t)(nband + r) * lda + col] = v;
+}
+__global__ __launch_bounds__(256) void k_band_tiles_finish(const double* __restrict__ A, int64_t sA, int lda, int nband, int nrhs,
+                                                           double* __restrict__ logdet, double* __restrict__ gram) {
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* Ab = A + (int64_t)b * sA;
+    double acc = 0.0;
+    for (int i = tid; i < nband; i += 256) acc += log(Ab[(int64_t)i * lda + i]);
+    red[tid] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) logdet[b] = 2.0 * red[0];
+    for (int e = tid; e < nrhs * nrhs; e += 256) {
+        const int r = e / nrhs, c = e - r * nrhs;
+        gram[(int64_t)b * nrhs * nrhs + e] = -Ab[(int64_t)(nband + max(r, c)) * lda + nband + min(r, c)];
+    }
+}
+
+int sf_band_tiles_lda(int nband) { return nband + 64 + 16; }
+int sf_band_tiles_wt(int halfwidth) { return (halfwidth + GT - 1) / GT; }
+size_t sf_band_tiles_doubles(int nband, int batch) {  // the dense-strided array + the factorisation's scratch
+    return (size_t)batch * (nband + 64) * sf_band_tiles_lda(nband) + sf_potrf_work_doubles(nband + 64, batch) + 64;
+}
+
+// band: [batch] x sband compact band storage (band[i * ldb + d] = Bd[i][i - d]), or NULL when the lower tiles
+// that meet the band are already in place at the start of `tiles` (row stride sf_band_tiles_lda(nband), matrix stride
+// (nband + 64) rows; lower triangle, zeros where the band ends inside a tile, identity padding); rhs0 / rhs: the right-hand sides
+// (row 0 separate, as in sf_launch_band_forms); n = order of the data, nband = n rounded up to 64 (identity
+// padded); `tiles` needs sf_band_tiles_doubles(nband, batch) doubles.  Outputs logdet(Bd) and the nrhs x nrhs Gram
+// matrix of the solved right-hand sides; info[b] (cleared by the caller) gets the first non-positive pivot.
+int sf_launch_potrf_band(const double* band, int n, int nband, int halfwidth, int ldb, int64_t sband, int batch,
+                         const double* rhs0, int64_t srhs0, const double* rhs, int nrhs, int ldr, int64_t srhs,
+                         double* logdet, double* gram, int* info, double* tiles, hipStream_t s, sf_exec* ex) {
+    if (nband % SF_LEAF != 0 || nband < n || batch <= 0 || nrhs < 1 || nrhs > 64 || halfwidth < 0 || !tiles) {
+        sf_set_error("potrf_band: bad arguments (n=%d nband=%d halfwidth=%d nrhs=%d)", n, nband, halfwidth, nrhs);
+        return SF_EINVAL;
+    }
+    (void)ex;
+    const int next = nband + 64, lda = sf_band_tiles_lda(nband);
+    const int64_t sA = (int64_t)next * lda;
+    double* A = tiles;
+    double* work = tiles + (size_t)batch * sA;
+    const int nt = (nband + GT - 1) / GT;
+    const int wt = sf_band_tiles_wt(halfwidth);
+    static const bool poison = getenv("SF_BAND_TILES_POISON") != nullptr;  // test aid: NaN wherever something is read before it is written
+    if (poison && band) SF_HIP(hipMemsetAsync(tiles, 0xff, sizeof(double) * sf_band_tiles_doubles(nband, batch), s));
+    if (band) {  // compact band storage given: spread it over the tiles (NULL: the caller filled the tiles, k_band_fill's tile mode)
+        hipLaunchKernelGGL(k_band_to_tiles, dim3(wt + 1, nt, batch), dim3(256), 0, s, band, sband, ldb, halfwidth, n, nband, wt, A, sA, lda);
+        SF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_band_border_rows, dim3((next + 255) / 256, 64, batch), dim3(256), 0, s, rhs0, srhs0, rhs, srhs, ldr, nrhs, n,
+                       nband, A, sA, lda);
+    SF_LAUNCH_CHECK();
+
+    double* T = work + (size_t)batch * SF_LTB_DOUBLES;
+    const int64_t sT = (int64_t)(next + SF_NB) * SF_LDT + SF_TSKEW;
+    double* Wt = T + (size_t)batch * sT;
+    const int64_t sW = (int64_t)SF_NB * SF_LDT + SF_TSKEW;
+    // (info is NOT cleared here: the band fill may have flagged a half-width that is too small; a non-zero entry stays)
+    // One stream, two launches per panel: the launches are short (a few slabs, K <= halfwidth + 128), so the
+    // lookahead of the dense sequence has nothing to hide behind -- measured with the chain on a side stream:
+    // 13.4 ms against 9.4 at W = 361 (cross-stream waits cost more than the kernels they overlap).
+    auto launch_panel = [&](int k0, int pw, int row0, int nslab, bool border) -> int {
+        sf_panel_args g = {};
+        g.C = A;
+        g.sC = sA;
+        g.lda = lda;
+        g.n = next;
+        g.k0 = k0;
+        g.pw = pw;
+        g.row0 = row0;
+        g.nslab = nslab + (border ? 1 : 0);
+        g.slab_step = 1;
+        g.Wt = Wt;
+        g.sW = sW;
+        g.kband = halfwidth > 0 ? halfwidth : 1;
+        g.nband = nband;
+        g.xrow0 = border ? nband : 0;
+        if (nslab > 0) {  // the first slab is the next diagonal tile: its update is parked in the scratch for D(k+1)
+            g.Sout = T;
+            g.sS = sT;
+            g.ldS = SF_LDT;
+        }
+        const long long nblk = (long long)g.nslab * batch;
+        if (nblk <= 0) return SF_OK;
+        void* tok;
+        sf_prof_gemm_begin(s, 2.0 * (double)min(k0, halfwidth + GT) * GT * pw * (double)nblk, &tok);
+        hipLaunchKernelGGL((k_chol_panel<false, 0>), dim3((unsigned)nblk), dim3(512), 0, s, g);
+        sf_prof_gemm_end(tok);
+        SF_LAUNCH_CHECK();
+        return SF_OK;
+    };
+    SF_TRY(launch_panel(0, 0, 0, 1, false));  // diagonal tile 0 goes to the scratch unchanged
+    for (int k = 0; k < nt; ++k) {
+        const int k0 = k * GT;
+        const int pw = (nband - k0 < GT) ? nband - k0 : GT;
+        hipLaunchKernelGGL(k_diag_mfma<512>, dim3(batch), dim3(512), 0, s, T, sT, pw, info, k0, (double*)nullptr, 0,
+                           A + (int64_t)k0 * lda + k0, lda, sA, Wt, sW);
+        SF_LAUNCH_CHECK();
+        // the slabs k+1 .. k+wt that meet the band, and the border
+        const int last = (k + wt < nt - 1) ? k + wt : nt - 1;
+        SF_TRY(launch_panel(k0, pw, (k + 1) * GT, last - k, true));
+    }
+    hipLaunchKernelGGL(k_band_tiles_finish, dim3(batch), dim3(256), 0, s, A, sA, lda, nband, nrhs, logdet, gram);
+    SF_LAUNCH_CHECK();
     return SF_OK;
 }
 

@@ -81,6 +81,12 @@ struct sf_gen_args {
 };
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
                     double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen = nullptr, sf_exec* ex = nullptr);
+int sf_band_tiles_lda(int nband);
+size_t sf_band_tiles_doubles(int nband, int batch);
+int sf_band_tiles_wt(int halfwidth);  // tile (i, j) of a bordered band matrix meets the band iff i - j <= wt
+int sf_launch_potrf_band(const double* band, int n, int nband, int halfwidth, int ldb, int64_t sband, int batch,
+                         const double* rhs0, int64_t srhs0, const double* rhs, int nrhs, int ldr, int64_t srhs,
+                         double* logdet, double* gram, int* info, double* tiles, hipStream_t s, sf_exec* ex);
 int sf_set_cholesky_sequence(int mode);  // -1 automatic (by batch size), 0 fused panel kernel, 1 unfused
 int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batch, const double* z, int ldr,
                        double* logdet, double* sqmah, hipStream_t s);
@@ -110,7 +116,7 @@ struct sf_fill_args {
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);
 // band storage of the structured part of C (sf_band.hip consumes it); a.npad = rows written (>= a.n)
 int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int halfwidth, int ldb, int64_t sband,
-                        int* info, double* gtab, hipStream_t s);  // ws stored diagonals > halfwidth; gtab: B x (ws+1) or NULL
+                        int* info, double* gtab, hipStream_t s, int tile_wt = -1);  // ws stored diagonals > halfwidth; gtab: B x (ws+1) or NULL
 int sf_launch_global_cov(const double* wave, int n, double amp, double ls, double* out, hipStream_t s);
 int sf_launch_local_cov(const double* wave, int n, double amp, double mu, double sigma, int accumulate,
                         double* out, hipStream_t s);

@@ -311,9 +311,12 @@ __global__ __launch_bounds__(256) void k_band_gtab(sf_fill_args a, double* __res
 }
 
 #define SF_BF_ROWS 32
+// tile_wt < 0: compact band storage band[i * ldb + d].  tile_wt >= 0: the same values straight into the lower
+// 128 x 128 tiles of a dense-strided array (row stride ldb) that meet the band -- element (i, i - d), d < ws =
+// 128 (tile_wt + 1), as far left as the first tile column (i / 128 - tile_wt) of the row (sf_launch_potrf_band).
 __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __restrict__ band, int ws, int hw, int ldb,
                                                    int64_t sband, int* __restrict__ info,
-                                                   const double* __restrict__ gtab) {
+                                                   const double* __restrict__ gtab, int tile_wt) {
     // per-walker constants once per block: exp() of the hyper-parameters (spectrum_model.py:343-357)
     __shared__ double s_glob[4];                 // amp, r0, 1/r0, sqrt(3)/ls
     __shared__ double s_loc[SF_MAX_LOCAL][6];    // mu, amp, r0, 1/r0, -0.5/sigma^2, c/mu
@@ -342,9 +345,12 @@ __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __res
     const int lane = tid & 63;
     const double* __restrict__ gt = gtab ? gtab + (int64_t)b * (ws + 1) : nullptr;
     for (int i = blockIdx.x * SF_BF_ROWS + (tid >> 6); i < min(a.npad, (int)(blockIdx.x + 1) * SF_BF_ROWS); i += 4) {
-        double* __restrict__ dst = band + (int64_t)b * sband + (int64_t)i * ldb;
+        const bool tiled = tile_wt >= 0;
+        double* __restrict__ dst = band + (int64_t)b * sband + (int64_t)i * ldb + (tiled ? i : 0);
+        const int dmax = tiled ? i - max((i >> 7) - tile_wt, 0) * 128 : ws - 1;  // last stored diagonal of this row
+        const int dstep = tiled ? -1 : 1;
         if (i >= a.n) {
-            for (int d = lane; d < ws; d += 64) dst[d] = (d == 0) ? 1.0 : 0.0;  // identity padding
+            for (int d = lane; d <= min(dmax, ws - 1); d += 64) dst[dstep * d] = (d == 0) ? 1.0 : 0.0;  // identity padding
             continue;
         }
         const double w_row = a.wave[i];
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __res
             }
             return acc;
         };
-        for (int d = lane; d < ws; d += 64) {
+        for (int d = lane; d <= min(dmax, ws - 1); d += 64) {
             const int j = i - d;
             double v = 0.0;
             if (j >= 0 && d <= hw) {  // diagonals past the caller's half-width are stored as zeros, never as data
@@ -395,13 +401,13 @@ __global__ __launch_bounds__(256) void k_band_fill(sf_fill_args a, double* __res
                     if (outside) atomicCAS(info + b, 0, SF_INFO_BANDWIDTH);
                 }
             }
-            dst[d] = v;
+            dst[dstep * d] = v;
         }
     }
 }
 
 int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int halfwidth, int ldb, int64_t sband,
-                        int* info, double* gtab, hipStream_t s) {
+                        int* info, double* gtab, hipStream_t s, int tile_wt) {
     if (halfwidth < 0 || halfwidth >= ws) {
         sf_set_error("band fill: half-width %d does not fit the %d stored diagonals", halfwidth, ws);
         return SF_EINVAL;
@@ -420,7 +426,7 @@ int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int 
         SF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_band_fill, dim3((unsigned)((a.npad + SF_BF_ROWS - 1) / SF_BF_ROWS), B), dim3(256), 0, s, a, band, ws, halfwidth, ldb, sband,
-                       info, table ? (const double*)gtab : nullptr);
+                       info, table ? (const double*)gtab : nullptr, tile_wt);
     SF_LAUNCH_CHECK();
     return SF_OK;
 }

@@ -1,5 +1,5 @@
 """Time the structure-exploiting solver (sf_loglike_banded_batch) at a BASELINE config and compare with
-the dense path.  Usage: python tools/bench_banded.py [npix] [batch] [steps]"""
+the dense path.  Usage: [SF_BENCH_LS=km/s] python tools/bench_banded.py [npix] [batch] [steps]"""
 import ctypes as C
 import os
 import sys
@@ -23,6 +23,9 @@ oo = oracle_order(order)
 do = device_order(oo)
 P = synth.walker_ball(order, B=B, seed=1)
 plist = [synth.vector_to_oracle_params(p) for p in P]
+if os.environ.get("SF_BENCH_LS"):  # wider global kernel: half-width = 24 ls / dv pixels
+    for p in plist:
+        p["global_cov"] = (p["global_cov"][0], float(np.log(float(os.environ["SF_BENCH_LS"]))))
 md, rows = pack_rows(do, plist)
 hw = int(do.halfwidth_bound(md, rows).max())
 P_dev = D.to_dev(rows, do.dev)
