@@ -368,6 +368,36 @@ def main():
                 "so the dense MFMA roofline above does not apply to it",
             }
 
+            # the same walkers with a wider global kernel (ls = 30 km/s: half-width 24 ls / dv = 361 px, beyond the LDS
+            # window): the bordered-band factorisation on the dense path's panel kernel (sf_launch_potrf_band)
+            labels = list(model.labels)
+            if "global_cov:log_ls" in labels and not custom:
+                Pw = np.array(P, dtype=float, copy=True)
+                Pw[:, labels.index("global_cov:log_ls")] = np.log(30.0)
+                _, md_w, rows_w = model._pack(Pw, update_caches=False)
+                hw_w = int(dev.halfwidth_bound(md_w, rows_w).max())
+                if dev.banded_window_halfwidth() < hw_w <= dev.banded_max_halfwidth():
+                    Pw_dev = D.to_dev(rows_w, dev.dev)
+                    dense_w = D.empty((n_local,), dev.dev)
+                    dev.loglike_device(md_w, Pw_dev, dense_w, info_b)
+                    for _ in range(2):
+                        dev.loglike_banded_device(md_w, Pw_dev, hw_w, lnl_b, info_b)
+                    torch.cuda.synchronize()
+                    tw = time.perf_counter()
+                    for _ in range(5):
+                        dev.loglike_banded_device(md_w, Pw_dev, hw_w, lnl_b, info_b)
+                    torch.cuda.synchronize()
+                    dtw = (time.perf_counter() - tw) / 5
+                    lw, dw = lnl_b.cpu().numpy(), dense_w.cpu().numpy()
+                    assert (info_b.cpu().numpy() == 0).all()
+                    rel_w = float(np.max(np.abs(lw - dw) / np.abs(dw)))
+                    assert rel_w < 1e-9, rel_w
+                    structured["wide_band"] = {
+                        "global_ls_kms": 30.0, "band_halfwidth_px": hw_w, "ms_per_step": dtw * 1e3,
+                        "value": n_local / dtw, "unit": "evals/s per GPU", "max_rel_dlnl_vs_dense_path": rel_w,
+                        "kernel": "bordered band matrix on k_diag_mfma + k_chol_panel, K loops limited to the band",
+                    }
+
     if rank == 0:
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 as the
         # micro-arch guide prescribes for gfx950, + WRITE_SIZE) summarised under profiles/ by
