@@ -908,6 +908,159 @@ __global__ __launch_bounds__(NT) void k_diag_mfma(double* __restrict__ T, int64_
 }
 
 
+// The same diagonal-block step for the 128-column panels of the fused sequence, with the tile and its growing inverse
+// RESIDENT IN LDS (36 + 36 blocks of 16 x 17 doubles: 157 KB): k_diag_mfma keeps them in the L2-backed scratch, so
+// every one of its 8 block columns pays two global round trips (stage L(k,:), write X / read it back as an operand
+// of the next column), 55-65 us per tile when the chip is idle and three times that beside the panel launches.
+// Here the tile is read once, the eight columns run out of LDS (no staging buffers: an accumulator block is written
+// to its own destination block and read back in operand layout by the same wave), and L / L^-1 / z are written once.
+// One workgroup owns a CU while it runs (LDS), for a fraction of the time the old kernel held a slot.
+__global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, int64_t sT, int pw, int* __restrict__ info,
+                                                  int info_off, double* __restrict__ rhs, int ldr,
+                                                  double* __restrict__ Cdiag, int ldc, int64_t sC,
+                                                  double* __restrict__ Wt, int64_t sW) {
+    extern __shared__ double dsm[];
+    double* Tl = dsm;              // lower blocks (bi >= bj) of the tile at (bi (bi + 1) / 2 + bj) * DBS
+    double* El = Tl + 36 * DBS;    // blocks X(e, j), e <= j, of W = L_kk^-T at (j (j + 1) / 2 + e) * DBS
+    double* Fb = El + 36 * DBS;    // inverse of the current 16 x 16 diagonal factor
+    double* rz = Fb + DBS;         // [128]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nb = pw >> 4;
+    const double* Tb = T + (int64_t)b * sT;
+    double* Cb = Cdiag + (int64_t)b * sC;
+    double* Wb = Wt + (int64_t)b * sW;
+    auto tb = [](int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * DBS; };
+    auto eb = [](int e, int j) { return (j * (j + 1) / 2 + e) * DBS; };
+
+    for (int idx = tid; idx < nb * nb * 256; idx += 512) {
+        const int blk = idx >> 8, bi = blk / nb, bj = blk - bi * nb, r = (idx >> 4) & 15, c = idx & 15;
+        if (bj <= bi) Tl[tb(bi, bj) + r * DLD + c] = Tb[(int64_t)(16 * bi + r) * SF_LDT + 16 * bj + c];
+    }
+    __syncthreads();
+    int bad = 0;
+    const int oF = l15 * DLD + lq;  // operand fragment: row l15, K slice lq of instruction kk stands for k = 4 kk + lq
+    for (int k = 0; k < nb; ++k) {
+        const int m = nb - 1 - k;
+        // ---- U: wave t <= m holds M(k + t, k), wave t > m the block X(t - m - 1, k) of the inverse
+        const int t = wave;
+        const bool has = t <= m + k, isM = t <= m;
+        const int ib = isM ? k + t : t - m - 1;
+        double* own = has ? (isM ? Tl + tb(ib, k) : El + eb(ib, k)) : Fb;
+        sf_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (has) {
+            if (isM) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = lq + 4 * r;  // (the diagonal block is read symmetrically from its lower triangle)
+                    acc[r] = t == 0 ? own[max(row, l15) * DLD + min(row, l15)] : own[row * DLD + l15];
+                }
+            }
+            for (int j = isM ? 0 : ib; j < k; ++j) {
+                const double* ap = (isM ? Tl + tb(ib, j) : El + eb(ib, j)) + oF;
+                const double* bp = Tl + tb(k, j) + oF;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[4 * kk], acc, 0, 0, 1);  // neg:[1,0,0]
+            }
+        }
+        // ---- P: wave 0 factorises the diagonal block and inverts the factor in the accumulator layout
+        if (wave == 0) {
+            sf_d4 a0 = acc, f, lt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f[r] = (lq + 4 * r) == l15 ? 1.0 : 0.0;
+                lt[r] = 0.0;
+            }
+            double p = sf_readlane_d(a0[0], 0);
+            double pkeep = 1.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int qj = j & 3, rj = j >> 2;
+                pkeep = lane == j ? p : pkeep;
+                const double rs = sfd_rsqrt(p);
+                const bool in_q = lq == qj;
+                const double v = (in_q && l15 > j) ? a0[rj] * rs : 0.0;  // l_ij, i = l15 > j
+                const double g = in_q ? f[rj] * rs : 0.0;                // row j of F, scaled
+                if (in_q) {
+                    f[rj] = g;
+                    lt[rj] = l15 == j ? p * rs : v;  // L^T[j][i]
+                }
+                if (j + 1 < 16) {
+                    const double an = sf_readlane_d(a0[(j + 1) >> 2], ((j + 1) & 3) * 16 + j + 1);
+                    const double vn = sf_readlane_d(v, qj * 16 + j + 1);
+                    p = __builtin_fma(-vn, vn, an);
+                }
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, a0, 0, 0, 1);  // neg:[1,0,0]
+                f = __builtin_amdgcn_mfma_f64_16x16x4f64(v, g, f, 0, 0, 1);
+            }
+            const unsigned long long neg = __ballot(lane < 16 && !(pkeep > 0.0));
+            if (neg && !bad) bad = 16 * k + __ffsll((long long)neg);
+            double* Ekk = El + eb(k, k);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = lq + 4 * r;
+                Fb[row * DLD + l15] = f[r];
+                Ekk[l15 * DLD + row] = f[r];                      // X of the identity row block k is F^T
+                if (l15 >= row) own[l15 * DLD + row] = lt[r];     // L[i][j], lower triangle of the diagonal block
+            }
+        }
+        __syncthreads();
+        // ---- X: the other blocks times F^T, through their own destination block (accumulator -> operand layout)
+        if (has && wave != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) own[(lq + 4 * r) * DLD + l15] = acc[r];
+            double a[4], f4[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                a[kk] = own[oF + 4 * kk];
+                f4[kk] = Fb[oF + 4 * kk];
+            }
+            sf_d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], f4[kk], x, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) own[(lq + 4 * r) * DLD + l15] = x[r];
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && bad && info && info[b] == 0) info[b] = info_off + bad;
+    // ---- L -> matrix (lower triangle), Wt[c][j] = (L_kk^-1)[c][j] (block (cb, jb) = X(jb, cb)^T, zero above)
+    for (int idx = tid; idx < nb * nb * 256; idx += 512) {
+        const int blk = idx >> 8, bi = blk / nb, bj = blk - bi * nb, r = (idx >> 4) & 15, c = idx & 15;
+        if (bj < bi || (bj == bi && c <= r)) Cb[(int64_t)(16 * bi + r) * ldc + 16 * bj + c] = Tl[tb(bi, bj) + r * DLD + c];
+        Wb[(int64_t)(16 * bi + r) * SF_LDT + 16 * bj + c] = bj <= bi ? El[eb(bj, bi) + c * DLD + r] : 0.0;
+    }
+    // ---- z_k = L_kk^-1 r_k with the explicit inverse
+    if (rhs) {
+        double* rb = rhs + (int64_t)b * ldr;
+        if (tid < pw) rz[tid] = rb[tid];
+        __syncthreads();
+        if (tid < pw) {
+            const int i = tid, ibk = i >> 4, ir = i & 15;
+            double zacc = 0.0;
+            for (int j = 0; j <= i; ++j) zacc = __builtin_fma(El[eb(j >> 4, ibk) + (j & 15) * DLD + ir], rz[j], zacc);
+            rb[i] = zacc;
+        }
+    }
+}
+#define SF_DIAG_LDS_BYTES ((73 * DBS + 128) * sizeof(double))
+static int sf_launch_diag128(double* T, int64_t sT, int pw, int* info, int info_off, double* rhs, int ldr, double* Cdiag,
+                             int ldc, int64_t sC, double* Wt, int64_t sW, int batch, hipStream_t s) {
+    static const bool scratch = getenv("SF_DIAG_SCRATCH") != nullptr;  // tuning aid: the L2-resident k_diag_mfma<512>
+    if (scratch) {
+        hipLaunchKernelGGL(k_diag_mfma<512>, dim3(batch), dim3(512), 0, s, T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc, sC, Wt, sW);
+    } else {
+        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
+        if (sf_first_use_on_device(&attr_seen))
+            SF_HIP(hipFuncSetAttribute((const void*)k_diag_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(k_diag_lds, dim3(batch), dim3(512), SF_DIAG_LDS_BYTES, s, T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc,
+                           sC, Wt, sW);
+    }
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused left-looking panel step (panel width = tile edge = 128).  One workgroup owns a 128-row slab
 // of the panel [k0, k0 + pw) and does, without leaving the CU:
@@ -1738,9 +1891,8 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
         if (c != s || G > 1)
             for (int g = 0; g < G; ++g)
                 if (e_rest_prev[g] && (c != gs[g])) SF_HIP(hipStreamWaitEvent(c, e_rest_prev[g], 0));
-        hipLaunchKernelGGL(k_diag_mfma<512>, dim3(batch), dim3(512), 0, c, T, sT, pw, info, k0,
-                           rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
-        SF_LAUNCH_CHECK();
+        SF_TRY(sf_launch_diag128(T, sT, pw, info, k0, rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW,
+                                 batch, c));
         if (k + 1 >= nt) break;
         hipEvent_t e_d;
         SF_TRY(sf_exec_event(ex, &e_d));
@@ -1913,9 +2065,7 @@ int sf_launch_potrf_band(const double* band, int n, int nband, int halfwidth, in
     for (int k = 0; k < nt; ++k) {
         const int k0 = k * GT;
         const int pw = (nband - k0 < GT) ? nband - k0 : GT;
-        hipLaunchKernelGGL(k_diag_mfma<512>, dim3(batch), dim3(512), 0, s, T, sT, pw, info, k0, (double*)nullptr, 0,
-                           A + (int64_t)k0 * lda + k0, lda, sA, Wt, sW);
-        SF_LAUNCH_CHECK();
+        SF_TRY(sf_launch_diag128(T, sT, pw, info, k0, nullptr, 0, A + (int64_t)k0 * lda + k0, lda, sA, Wt, sW, batch, s));
         // the slabs k+1 .. k+wt that meet the band, and the border
         const int last = (k + wt < nt - 1) ? k + wt : nt - 1;
         SF_TRY(launch_panel(k0, pw, (k + 1) * GT, last - k, true));

@@ -174,9 +174,11 @@ def test_cfg2_full_size_n4096_vs_reference(chol_sequence):
     for b in range(len(P)):
         assert close_lnl(out["lnl"][1 + b], g["n4096_batch_lnl"][b])
     # size-independent properties at full size: replicas agree bit for bit, order in the batch is irrelevant
+    # (across DIFFERENT batch sizes the split-K factor of the late panels may differ: same value to rounding only)
     rep = do.loglike(md, np.repeat(rows[:2], 3, axis=0))
-    assert rep["lnl"][0] == rep["lnl"][1] == rep["lnl"][2] == out["lnl"][0]
-    assert rep["lnl"][3] == rep["lnl"][4] == rep["lnl"][5] == out["lnl"][1]
+    assert rep["lnl"][0] == rep["lnl"][1] == rep["lnl"][2]
+    assert rep["lnl"][3] == rep["lnl"][4] == rep["lnl"][5]
+    np.testing.assert_allclose(rep["lnl"][[0, 3]], out["lnl"][:2], rtol=1e-12)
     fw = do.forward(md, rows[:1])
     cov = fw["cov"][0]
     np.testing.assert_allclose(cov.diagonal(), g["n4096_diag"], rtol=1e-10)
