@@ -16,3 +16,33 @@ def get_w_hat(eigenspectra, fluxes):
     F = np.asarray(fluxes, dtype=np.float64)
     rhs = (E @ F.T).reshape(-1)
     return np.linalg.solve(get_phi_squared(E, len(F)), rhs)
+
+
+def get_altered_prior_factors(eigenspectra, fluxes):
+    """Shape and rate of the Gamma prior on lambda_xi after the reconstruction error of the library has been
+    absorbed (Czekala et al. 2015, eqs. A24-A25; Starfish/emulator/_utils.py:51-82):
+    a' = M (N_pix - m) / 2,   b' = (F.F - F.(Phi w_hat)) / 2."""
+    E = np.asarray(eigenspectra, dtype=np.float64)
+    F = np.asarray(fluxes, dtype=np.float64)
+    M, npix = F.shape
+    m = len(E)
+    recon = get_w_hat(E, F).reshape(m, M).T @ E  # row i: sum_j w_hat[j M + i] e_j
+    return 0.5 * M * (npix - m), 0.5 * float(np.sum(F * F) - np.sum(F * recon))
+
+
+class Gamma:
+    """Gamma(alpha, rate beta) density, the prior family of the emulator's lambda_xi
+    (Starfish/emulator/_utils.py:85-101)."""
+
+    def __init__(self, alpha, beta=1):
+        self.alpha = alpha
+        self.beta = beta
+
+    def logpdf(self, x):
+        from scipy.special import gammaln
+
+        x = np.asarray(x, dtype=np.float64)
+        return self.alpha * np.log(self.beta) - gammaln(self.alpha) + (self.alpha - 1) * np.log(x) - self.beta * x
+
+    def pdf(self, x):
+        return np.exp(self.logpdf(x))

@@ -250,7 +250,20 @@ class Emulator:
     # ----------------------------------------------------------------- persistence
     @classmethod
     def load(cls, filename):
-        """HDF5 layout of Starfish/emulator/emulator.py:188-231 (needs h5py)."""
+        """HDF5 layout of Starfish/emulator/emulator.py:188-231 (needs h5py); a file name ending in ``.npz`` is
+        read as the numpy container `save` writes when h5py is not installed (same keys)."""
+        filename = os.path.expandvars(filename)
+        if str(filename).endswith(".npz"):
+            with np.load(filename, allow_pickle=False) as base:
+                kw = {k: base[k] for k in ("grid_points", "wavelength", "weights", "eigenspectra", "flux_mean", "flux_std",
+                                           "w_hat", "factors", "variances", "lengthscales")}
+                kw["param_names"] = [str(n) for n in base["param_names"]]
+                kw["lambda_xi"] = float(base["lambda_xi"])
+                trained = bool(base["trained"])
+                name = str(base["name"]) if "name" in base.files else ".".join(str(filename).split(".")[:-1])
+            emu = cls(name=name, **kw)
+            emu._trained = trained
+            return emu
         try:
             import h5py
         except ImportError as e:  # pragma: no cover - h5py is absent on the GPU box
@@ -278,7 +291,17 @@ class Emulator:
         return emu
 
     def save(self, filename):
-        """HDF5 layout of Starfish/emulator/emulator.py:233-270 (needs h5py)."""
+        """HDF5 layout of Starfish/emulator/emulator.py:233-270 (needs h5py); ``*.npz``: the same keys in a numpy
+        container (no h5py needed)."""
+        filename = os.path.expandvars(filename)
+        if str(filename).endswith(".npz"):
+            extra = {} if self.name is None else {"name": np.array(self.name)}
+            np.savez_compressed(
+                filename, grid_points=self.grid_points, param_names=np.array(list(self.param_names)), wavelength=self.wl,
+                weights=self.weights, eigenspectra=self.eigenspectra, flux_mean=self.flux_mean, flux_std=self.flux_std,
+                w_hat=self.w_hat, factors=self.factors, lambda_xi=np.array(self.lambda_xi), variances=self.variances,
+                lengthscales=self.lengthscales, trained=np.array(bool(self._trained)), **extra)
+            return
         try:
             import h5py
         except ImportError as e:  # pragma: no cover

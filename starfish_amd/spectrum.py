@@ -133,7 +133,12 @@ class Spectrum:
 
     @classmethod
     def load(cls, filename):
-        """Load from HDF5 with keys waves/fluxes/sigmas/masks (Starfish/spectrum.py:222-245)."""
+        """Load from HDF5 with keys waves/fluxes/sigmas/masks (Starfish/spectrum.py:222-245); ``*.npz``: the numpy
+        container `save` writes without h5py (same keys)."""
+        if str(filename).endswith(".npz"):
+            with np.load(filename, allow_pickle=False) as base:
+                name = str(base["name"]) if "name" in base.files else None
+                return cls(base["waves"], base["fluxes"], base["sigmas"], base["masks"], name=name)
         try:
             import h5py
         except ImportError as e:  # pragma: no cover - h5py is absent on the GPU box
@@ -143,7 +148,11 @@ class Spectrum:
             return cls(base["waves"][:], base["fluxes"][:], base["sigmas"][:], base["masks"][:], name=name)
 
     def save(self, filename):
-        """Write to HDF5 (Starfish/spectrum.py:247-267)."""
+        """Write to HDF5 (Starfish/spectrum.py:247-267), or to a numpy container when the name ends in ``.npz``."""
+        if str(filename).endswith(".npz"):
+            extra = {} if self.name is None else {"name": np.array(self.name)}
+            np.savez_compressed(filename, waves=self._waves, fluxes=self._fluxes, sigmas=self._sigmas, masks=self.masks, **extra)
+            return
         try:
             import h5py
         except ImportError as e:  # pragma: no cover

@@ -1,0 +1,133 @@
+"""Behaviours of the small emulator / spectrum / utils helpers that the reference's suite exercises
+(tests/test_emulator/test_utils.py, test_kernels.py, test_emulator.py, tests/test_spectrum.py, tests/test_utils.py),
+restated for this package.  All host logic: runs without a GPU."""
+import os
+
+import numpy as np
+import pytest
+import scipy.stats as st
+
+from starfish_amd import Spectrum, synth
+from starfish_amd.emulator import Emulator
+from starfish_amd.emulator._utils import Gamma, get_altered_prior_factors, get_phi_squared, get_w_hat
+from starfish_amd.emulator.kernels import batch_kernel, rbf_kernel
+from starfish_amd.spectrum import Order
+from starfish_amd.utils import calculate_dv, calculate_dv_dict, create_log_lam_grid
+
+
+@pytest.fixture(scope="module")
+def library():
+    """A whitened synthetic library and its leading principal directions (what the reference's PCA set-up yields)."""
+    rng = np.random.default_rng(3)
+    lam = np.linspace(0, 1, 300)
+    F = np.array([1 + 0.3 * np.sin(7 * lam + a) + 0.1 * b * lam for a in (0, 0.4, 0.9, 1.5) for b in (-1, 0, 1)])
+    F += 1e-3 * rng.standard_normal(F.shape)
+    F /= F.mean(1, keepdims=True)
+    F -= F.mean(0)
+    F /= F.std(0)
+    _, _, vt = np.linalg.svd(F, full_matrices=False)
+    return vt[:4], F
+
+
+def test_w_hat_phi_squared_and_altered_prior(library):
+    eig, F = library
+    M, m = len(F), len(eig)
+    w_hat = get_w_hat(eig, F)
+    assert w_hat.shape == (M * m,) and np.all(np.isfinite(w_hat))
+    phi2 = get_phi_squared(eig, M)
+    assert phi2.shape == (M * m, M * m) and np.all(np.isfinite(phi2))
+    # Phi^T Phi of the explicit design matrix (component-major columns)
+    Phi = np.zeros((M * F.shape[1], M * m))
+    for i in range(M):
+        for j in range(m):
+            Phi[i * F.shape[1] : (i + 1) * F.shape[1], j * M + i] = eig[j]
+    assert np.allclose(Phi.T @ Phi, phi2)
+    assert np.allclose(np.linalg.lstsq(Phi, F.ravel(), rcond=None)[0], w_hat)
+    a, b = get_altered_prior_factors(eig, F)
+    assert a == 0.5 * M * (F.shape[1] - m)
+    assert np.isfinite(b) and np.isclose(b, 0.5 * (F.ravel() @ F.ravel() - F.ravel() @ (Phi @ w_hat)))
+
+
+@pytest.mark.parametrize("a,b", [(1, 0.001), (2, 0.075)])
+def test_gamma_density_matches_scipy(a, b):
+    x = np.linspace(1e-6, 1e4)
+    assert np.allclose(Gamma(a, b).logpdf(x), st.gamma(a, scale=1 / b).logpdf(x))
+    assert np.allclose(Gamma(a, b).pdf(x), st.gamma(a, scale=1 / b).pdf(x))
+
+
+def test_rbf_and_batch_kernels_shapes_and_symmetry():
+    rng = np.random.default_rng(0)
+    X = np.array([100.0, 1.0, 0.1]) * rng.standard_normal((60, 3)) + np.array([6000.0, 4.0, 0.0])
+    var, ls = np.ones(5), np.ones((5, 3))
+    K = rbf_kernel(X, X, var[0], ls[0])
+    assert K.shape == (60, 60) and np.allclose(K, K.T) and np.all(K.diagonal() >= 0) and np.allclose(K.diagonal(), var[0])
+    assert rbf_kernel(X, X[10:30], var[0], ls[0]).shape == (60, 20)
+    Kb = batch_kernel(X, X, var, ls)
+    assert Kb.shape == (300, 300) and np.allclose(Kb, Kb.T) and np.all(Kb.diagonal() >= 0)
+    assert np.allclose(Kb[60:120, 60:120], K) and not Kb[:60, 60:].any()  # block diagonal, one block per component
+    assert batch_kernel(X, X[10:30], var, ls).shape == (300, 100)
+
+
+def make_emulator(name="mock"):
+    o = synth.make_order(N=128, m=3, seed=2)
+    return Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"], o["w_hat"], o["flux_mean"],
+                    o["flux_std"], np.ones(len(o["grid_points"])), name=name)
+
+
+def test_emulator_hyper_parameters_and_persistence(tmp_path):
+    emu = make_emulator()
+    assert emu["log_lambda_xi"] == 0.0 and np.allclose(emu.variances, 1e4)
+    assert "log_variance:0" in emu.hyperparams and "log_lengthscale:0:0" in emu.hyperparams
+    P = emu.get_param_vector()
+    P[0] = 1.0
+    emu.set_param_vector(P)
+    assert np.allclose(emu.get_param_vector(), P)
+    D0 = emu.get_param_dict()
+    D0["log_lambda_xi"] = 0.5
+    emu.set_param_dict(D0)
+    assert emu.get_param_dict() == D0
+    assert emu.bulk_fluxes.shape == (emu.ncomps + 2, emu.eigenspectra.shape[-1])
+    assert str(emu).startswith("Emulator") and emu.get_index(emu.grid_points[4]) == 4
+    # round trip through the container that needs no h5py
+    emu._trained = True
+    path = os.path.join(tmp_path, "emu.npz")
+    emu.save(path)
+    back = Emulator.load(path)
+    assert back.get_param_dict() == emu.get_param_dict() and back._trained == emu._trained and back.name == emu.name
+    assert list(back.param_names) == list(emu.param_names)
+    for attr in ("grid_points", "wl", "weights", "eigenspectra", "w_hat", "flux_mean", "flux_std", "factors", "v11"):
+        assert np.array_equal(getattr(back, attr), getattr(emu, attr)), attr
+
+
+def test_order_and_spectrum_dunders_and_persistence(tmp_path):
+    wave = np.linspace(1e4, 2e4, 200)
+    flux = np.sin(wave)
+    assert np.all(Order(wave, flux)._sigma == 0.0) and np.all(Order(wave, flux).mask) and len(Order(wave, flux)) == 200
+    sp = Spectrum(wave, flux, name="single")
+    assert len(sp) == 1 and isinstance(sp[0], Order) and sp.shape == (1, 200)
+    sp.name = "special"
+    assert str(sp).startswith("special")
+    for i, order in enumerate(sp):
+        assert order == sp[i]
+    two = sp.reshape((2, -1))
+    assert two.shape == (2, 100) and two.name == "special"
+    two[0], two[1] = two[1], two[0]
+    assert np.allclose(two.waves[1], wave[:100])
+    with pytest.raises(ValueError):
+        sp[0] = two[0]
+    path = os.path.join(tmp_path, "data.npz")
+    two.save(path)
+    back = Spectrum.load(path)
+    for attr in ("waves", "fluxes", "sigmas", "masks"):
+        assert np.all(getattr(back, attr) == getattr(two, attr))
+    assert back.name == "special"
+
+
+def test_log_lambda_grid_helpers():
+    grid = create_log_lam_grid(1000, 3000, 3e4)
+    assert {"wl", "CRVAL1", "CDELT1", "NAXIS1"} <= set(grid)
+    for dv in (100, 1000, 10000):
+        g = create_log_lam_grid(dv, 1e4, 4e4)
+        assert np.isclose(calculate_dv(g["wl"]), calculate_dv_dict(g)) and calculate_dv(g["wl"]) <= dv
+    wave = np.linspace(1e4, 4e4)
+    assert np.isclose(calculate_dv(wave.tolist()), calculate_dv(wave)) and calculate_dv(wave) > 0
