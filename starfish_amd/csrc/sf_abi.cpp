@@ -1280,7 +1280,7 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         f.npad = (c->n + 15) / 16 * 16;
         const bool wide = halfwidth > sf_band_max_halfwidth(c->m + 1);
         if (bw.tiles) {  // straight into the 128 x 128 tiles of the bordered band matrix
-            static const bool poison = getenv("SF_BAND_TILES_POISON") != nullptr;  // test aid (see sf_launch_potrf_band)
+            static const bool poison = getenv("SF_BAND_TILES_POISON") != nullptr;  // test aid: NaN wherever a tile is read before it is written
             if (poison) SF_HIP(hipMemsetAsync(bw.tiles, 0xff, sizeof(double) * sf_band_tiles_doubles(c->npad, B), sf));
             f.npad = c->npad;
             const int lda_t = sf_band_tiles_lda(c->npad);
@@ -1301,9 +1301,8 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         ProfScope ps(s, PS_POTRF);
         const int n16 = (c->n + 15) / 16 * 16;
         if (bw.tiles)
-            rc = sf_launch_potrf_band(nullptr, c->n, c->npad, halfwidth, 0, 0, B, w.resid, c->npad, w.Y, c->m + 1,
-                                      c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band, bw.gram, w.info_c, bw.tiles, s,
-                                      &c->exec_potrf);
+            rc = sf_launch_potrf_band(c->n, c->npad, halfwidth, B, w.resid, c->npad, w.Y, c->m + 1, c->npad,
+                                      (int64_t)c->mpad * c->npad, bw.logdet_band, bw.gram, w.info_c, bw.tiles, s);
         else if (halfwidth > sf_band_max_halfwidth(c->m + 1))
             rc = sf_launch_band_wide(bw.band, n16, halfwidth, bw.ldb, sband, B, w.resid, c->npad, w.Y, c->m + 1,
                                      c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band, bw.gram, w.info_c, bw.twist, s);

@@ -1941,21 +1941,6 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
 // the dense path's rate, spread over the whole chip (k_band_wide keeps one matrix on one CU and streams its
 // operands from L2).  The border rows come out as Z = R L^-T, their diagonal tile as -Z Z^T: the Gram matrix the
 // Woodbury step needs; L_band's diagonal gives logdet(Bd).  The diagonal tile of the border is never factorised.
-__global__ __launch_bounds__(256) void k_band_to_tiles(const double* __restrict__ band, int64_t sband, int ldb, int halfwidth,
-                                                       int n, int nband, int wt, double* __restrict__ A, int64_t sA, int lda) {
-    const int b = blockIdx.z, ti = blockIdx.y, tj = ti - (int)blockIdx.x;  // tile (ti, tj), tj = ti - 0 .. ti - wt
-    if (tj < 0) return;
-    const double* bd = band + (int64_t)b * sband;
-    double* Ab = A + (int64_t)b * sA;
-    for (int e = threadIdx.x; e < GT * GT; e += 256) {
-        const int I = ti * GT + (e >> 7), J = tj * GT + (e & 127);
-        if (I >= nband || J >= nband) continue;
-        const int hi = max(I, J), d = hi - min(I, J);
-        double v = d == 0 ? 1.0 : 0.0;  // identity padding beyond the data
-        if (hi < n) v = d <= halfwidth ? bd[(int64_t)hi * ldb + d] : 0.0;
-        Ab[(int64_t)I * lda + J] = v;
-    }
-}
 // border rows: row 0 <- rhs0 (the residual), rows 1 .. nrhs-1 <- rhs rows, everything else (and the border's own
 // diagonal tile) zero
 __global__ __launch_bounds__(256) void k_band_border_rows(const double* __restrict__ rhs0, int64_t srhs0, const double* __restrict__ rhs,
@@ -1993,32 +1978,25 @@ size_t sf_band_tiles_doubles(int nband, int batch) {  // the dense-strided array
     return (size_t)batch * (nband + 64) * sf_band_tiles_lda(nband) + sf_potrf_work_doubles(nband + 64, batch) + 64;
 }
 
-// band: [batch] x sband compact band storage (band[i * ldb + d] = Bd[i][i - d]), or NULL when the lower tiles
-// that meet the band are already in place at the start of `tiles` (row stride sf_band_tiles_lda(nband), matrix stride
-// (nband + 64) rows; lower triangle, zeros where the band ends inside a tile, identity padding); rhs0 / rhs: the right-hand sides
-// (row 0 separate, as in sf_launch_band_forms); n = order of the data, nband = n rounded up to 64 (identity
-// padded); `tiles` needs sf_band_tiles_doubles(nband, batch) doubles.  Outputs logdet(Bd) and the nrhs x nrhs Gram
-// matrix of the solved right-hand sides; info[b] (cleared by the caller) gets the first non-positive pivot.
-int sf_launch_potrf_band(const double* band, int n, int nband, int halfwidth, int ldb, int64_t sband, int batch,
-                         const double* rhs0, int64_t srhs0, const double* rhs, int nrhs, int ldr, int64_t srhs,
-                         double* logdet, double* gram, int* info, double* tiles, hipStream_t s, sf_exec* ex) {
+// The lower 128 x 128 tiles that meet the band are in place at the start of `tiles` (k_band_fill's tile mode: row
+// stride sf_band_tiles_lda(nband), nband + 64 rows per matrix, zeros where the band ends inside a tile, identity
+// padding from n to nband = n rounded up to 64); `tiles` holds sf_band_tiles_doubles(nband, batch) doubles.  rhs0 /
+// rhs: the right-hand sides (row 0 separate, as in sf_launch_band_forms).  Outputs logdet(Bd) and the nrhs x nrhs
+// Gram matrix of the solved right-hand sides; info[b] (cleared by the caller) gets the first non-positive pivot.
+int sf_launch_potrf_band(int n, int nband, int halfwidth, int batch, const double* rhs0, int64_t srhs0, const double* rhs,
+                         int nrhs, int ldr, int64_t srhs, double* logdet, double* gram, int* info, double* tiles,
+                         hipStream_t s) {
     if (nband % SF_LEAF != 0 || nband < n || batch <= 0 || nrhs < 1 || nrhs > 64 || halfwidth < 0 || !tiles) {
         sf_set_error("potrf_band: bad arguments (n=%d nband=%d halfwidth=%d nrhs=%d)", n, nband, halfwidth, nrhs);
         return SF_EINVAL;
     }
-    (void)ex;
     const int next = nband + 64, lda = sf_band_tiles_lda(nband);
     const int64_t sA = (int64_t)next * lda;
     double* A = tiles;
     double* work = tiles + (size_t)batch * sA;
     const int nt = (nband + GT - 1) / GT;
     const int wt = sf_band_tiles_wt(halfwidth);
-    static const bool poison = getenv("SF_BAND_TILES_POISON") != nullptr;  // test aid: NaN wherever something is read before it is written
-    if (poison && band) SF_HIP(hipMemsetAsync(tiles, 0xff, sizeof(double) * sf_band_tiles_doubles(nband, batch), s));
-    if (band) {  // compact band storage given: spread it over the tiles (NULL: the caller filled the tiles, k_band_fill's tile mode)
-        hipLaunchKernelGGL(k_band_to_tiles, dim3(wt + 1, nt, batch), dim3(256), 0, s, band, sband, ldb, halfwidth, n, nband, wt, A, sA, lda);
-        SF_LAUNCH_CHECK();
-    }
+
     hipLaunchKernelGGL(k_band_border_rows, dim3((next + 255) / 256, 64, batch), dim3(256), 0, s, rhs0, srhs0, rhs, srhs, ldr, nrhs, n,
                        nband, A, sA, lda);
     SF_LAUNCH_CHECK();

@@ -84,9 +84,9 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
 int sf_band_tiles_lda(int nband);
 size_t sf_band_tiles_doubles(int nband, int batch);
 int sf_band_tiles_wt(int halfwidth);  // tile (i, j) of a bordered band matrix meets the band iff i - j <= wt
-int sf_launch_potrf_band(const double* band, int n, int nband, int halfwidth, int ldb, int64_t sband, int batch,
-                         const double* rhs0, int64_t srhs0, const double* rhs, int nrhs, int ldr, int64_t srhs,
-                         double* logdet, double* gram, int* info, double* tiles, hipStream_t s, sf_exec* ex);
+int sf_launch_potrf_band(int n, int nband, int halfwidth, int batch, const double* rhs0, int64_t srhs0, const double* rhs,
+                         int nrhs, int ldr, int64_t srhs, double* logdet, double* gram, int* info, double* tiles,
+                         hipStream_t s);
 int sf_set_cholesky_sequence(int mode);  // -1 automatic (by batch size), 0 fused panel kernel, 1 unfused
 int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batch, const double* z, int ldr,
                        double* logdet, double* sqmah, hipStream_t s);
