@@ -32,10 +32,9 @@
  *   - environment switches (tuning aids, read once): SF_NO_LOOKAHEAD=1 single-stream Cholesky,
  *     SF_CHOL_UNFUSED=1 the round-1 launch sequence (256-column panels, separate panel-solve and
  *     diagonal-update launches) instead of the fused panel kernel, SF_CHOL_GROUPS=1|2 slab groups,
- *     SF_CHOL_SPLIT=n split-K cap, SF_BAND_NO_TWIST=1 single-sweep banded solver, SF_BAND_TILES_FROM=px the
- *     half-width from which wide bands are factorised as bordered band matrices on the panel kernel (default 200;
- *     below it the in-place sweep), SF_BAND_TILES_POISON=1 NaN-fills their workspace first (test aid); with
- *     SF_CHOL_UNFUSED: SF_LEAF_DIAG=1, SF_GEMM_256=1 / SF_GEMM_1024=1 (see sf_chol.hip).
+ *     SF_CHOL_SPLIT=n split-K cap, SF_DIAG_SCRATCH=1 the L2-resident diagonal-tile kernel, SF_BAND_NO_TWIST=1
+ *     single-sweep banded solver, SF_BAND_TILES_POISON=1 NaN-fills the workspace of the wide-band factorisation
+ *     first (test aid); with SF_CHOL_UNFUSED: SF_LEAF_DIAG=1, SF_GEMM_256=1 / SF_GEMM_1024=1 (see sf_chol.hip).
  */
 #ifndef STARFISH_AMD_H
 #define STARFISH_AMD_H
@@ -275,10 +274,10 @@ int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf_model_desc
  * support is wider get info = SF_INFO_BANDWIDTH and lnl = -inf and must be re-run through
  * sf_loglike_batch.  Requires a strictly increasing wavelength grid and
  * halfwidth <= sf_banded_max_halfwidth(ctx).  Up to sf_banded_window_halfwidth(ctx) (144 px for
- * m <= 15) the band is swept through an LDS-resident window; wider bands are factorised in place in
- * HBM/L2 by a left-looking kernel (up to ~200 px) or, beyond that, as bordered band matrices on the
- * 128 x 128 tile kernels of the dense factorisation with K loops limited to the band -- their workspace
- * is as large as the dense path's (cost grows with halfwidth^2: group walkers by width).  Results
+ * m <= 15) the band is swept through an LDS-resident window; wider bands are factorised as bordered
+ * band matrices on the 128 x 128 tile kernels of the dense factorisation with K loops limited to the
+ * band -- their workspace is as large as the dense path's (cost grows with the half-width: group
+ * walkers by width).  Results
  * agree with the dense path to rounding (different summation order), not bit for bit. */
 int sf_banded_max_halfwidth(const sf_ctx* ctx);
 int sf_banded_window_halfwidth(const sf_ctx* ctx);

@@ -1185,14 +1185,6 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
 }
 
 // ------------------------------------------------------------------- structure-exploiting solver
-// Half-widths beyond the LDS window: up to ~200 px the in-place sweep k_band_wide (one CU per matrix) is the faster
-// one, beyond that the bordered-band factorisation on the fused panel kernel (cfg-2 shape, B = 128, ms per call of
-// the sweep / the tiles: W = 169: 4.6 / 5.2, 241: 7.5 / 5.7, 361: 10.3 / 7.4, 542: 18.5 / 11.1, 724: 30.1 / 12.7).
-// Tuning aid: SF_BAND_TILES_FROM=<px> moves the switch (0: always the tiles, 100000: never).
-static bool band_wide_on_tiles(int halfwidth) {
-    static const int from = getenv("SF_BAND_TILES_FROM") ? atoi(getenv("SF_BAND_TILES_FROM")) : 200;
-    return halfwidth >= from;
-}
 struct BandWork {
     double *band, *gram, *logdet_band, *twist, *gtab, *tiles;
     int ldb;
@@ -1203,14 +1195,14 @@ static BandWork carve_band(const sf_ctx* c, const sf_model_desc* mdl, int B, int
     Carve k(p, cap);
     k.off = base_bytes;
     BandWork w;
-    const bool wide = halfwidth > sf_band_max_halfwidth(c->m + 1);
-    const bool tiles = wide && band_wide_on_tiles(halfwidth);
-    w.ldb = tiles ? 128 * (sf_band_tiles_wt(halfwidth) + 1) : wide ? sf_band_wide_storage_width(halfwidth) : ((halfwidth + 2) & ~1);
+    // Half-widths beyond the LDS window are factorised as bordered band matrices on the tile kernels of the dense
+    // path (sf_launch_potrf_band); the band fill writes those tiles directly.
+    const bool tiles = halfwidth > sf_band_max_halfwidth(c->m + 1);
+    w.ldb = tiles ? 128 * (sf_band_tiles_wt(halfwidth) + 1) : ((halfwidth + 2) & ~1);
     w.band = tiles ? nullptr : k.take<double>((size_t)B * c->npad * w.ldb);  // (the tiles are filled directly)
     w.gram = k.take<double>((size_t)B * (c->m + 1) * (c->m + 1));
     w.logdet_band = k.take<double>((size_t)B);
-    w.twist = wide ? k.take<double>(sf_band_wide_work_doubles((c->n + 15) / 16 * 16, c->m + 1, B))
-                   : k.take<double>(sf_band_twisted_work_doubles(halfwidth, c->m + 1, B));
+    w.twist = tiles ? nullptr : k.take<double>(sf_band_twisted_work_doubles(halfwidth, c->m + 1, B));
     w.gtab = k.take<double>((size_t)B * (w.ldb + 2));
     w.tiles = tiles ? k.take<double>(sf_band_tiles_doubles(c->npad, B)) : nullptr;
     w.bytes = sf_align_up(k.off, 256);
@@ -1219,7 +1211,7 @@ static BandWork carve_band(const sf_ctx* c, const sf_model_desc* mdl, int B, int
 extern "C" int sf_banded_max_halfwidth(const sf_ctx* c) {
     if (!c || !c->n) return SF_EINVAL;
     if (!c->monotonic) return -1;
-    const int lds_max = sf_band_max_halfwidth(c->m + 1), wide_max = sf_band_wide_max_halfwidth();
+    const int lds_max = sf_band_max_halfwidth(c->m + 1), wide_max = SF_BAND_TILES_MAX_HALFWIDTH;
     return c->m + 1 <= 48 ? (wide_max > lds_max ? wide_max : lds_max) : lds_max;
 }
 extern "C" int sf_banded_window_halfwidth(const sf_ctx* c) {
@@ -1278,7 +1270,6 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         f.lower_only = 1;
         f.add_jitter = 1;
         f.npad = (c->n + 15) / 16 * 16;
-        const bool wide = halfwidth > sf_band_max_halfwidth(c->m + 1);
         if (bw.tiles) {  // straight into the 128 x 128 tiles of the bordered band matrix
             static const bool poison = getenv("SF_BAND_TILES_POISON") != nullptr;  // test aid: NaN wherever a tile is read before it is written
             if (poison) SF_HIP(hipMemsetAsync(bw.tiles, 0xff, sizeof(double) * sf_band_tiles_doubles(c->npad, B), sf));
@@ -1287,7 +1278,7 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
             rc = sf_launch_band_fill(f, B, bw.tiles, bw.ldb, halfwidth, lda_t, (int64_t)(c->npad + 64) * lda_t, w.info_c, bw.gtab, sf,
                                      sf_band_tiles_wt(halfwidth));
         } else
-            rc = sf_launch_band_fill(f, B, bw.band, wide ? bw.ldb : halfwidth + 1, halfwidth, bw.ldb, sband, w.info_c, bw.gtab, sf);
+            rc = sf_launch_band_fill(f, B, bw.band, halfwidth + 1, halfwidth, bw.ldb, sband, w.info_c, bw.gtab, sf);
         if (rc) return rc;
     }
     if (sf != s) SF_HIP(hipEventRecord(aux->join, sf));
@@ -1303,9 +1294,6 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         if (bw.tiles)
             rc = sf_launch_potrf_band(c->n, c->npad, halfwidth, B, w.resid, c->npad, w.Y, c->m + 1, c->npad,
                                       (int64_t)c->mpad * c->npad, bw.logdet_band, bw.gram, w.info_c, bw.tiles, s);
-        else if (halfwidth > sf_band_max_halfwidth(c->m + 1))
-            rc = sf_launch_band_wide(bw.band, n16, halfwidth, bw.ldb, sband, B, w.resid, c->npad, w.Y, c->m + 1,
-                                     c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band, bw.gram, w.info_c, bw.twist, s);
         else if (sf_band_twisted_applicable(n16, halfwidth, B))
             rc = sf_launch_band_forms_twisted(bw.band, n16, halfwidth, bw.ldb, sband, B, w.resid, c->npad, w.Y,
                                               c->m + 1, c->npad, (int64_t)c->mpad * c->npad, bw.logdet_band,

@@ -796,289 +796,6 @@ int sf_launch_band_forms_twisted(const double* band, int n, int halfwidth, int l
                                 (int64_t)NR * nm, logdet, gram, info, s, ladd, gadd, a.kend0 * BB);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Wide bands (W beyond the LDS window of k_band_forms, up to SF_BAND_WIDE_MAX): the band stays in HBM/L2
-// and is factorised IN PLACE, left-looking over 16-column block columns (the scheme of k_diag_mfma):
-//   stage  the row L(k, k-Wb .. k-1), shared B operand of the whole block column, into LDS
-//   U      every wave accumulates its blocks of column k in registers:  M(i,k) - sum_j L(i,j) L(k,j)^T for
-//          i = k .. k+Wb, and the right-hand-side row blocks  rhs(:,k) - sum_j Z(:,j) L(k,j)^T
-//          (A operands stream from L2: four 8-byte loads per lane and block, rotating prefetch)
-//   P      wave 0: 16 x 16 Cholesky + inverse in the MFMA accumulator layout
-//   X      every wave solves its blocks as products with the 16 x 16 inverse; L goes back into the band,
-//          the solved right-hand-side blocks Z into a scratch array (operands of the later columns)
-// and finally the Gram matrix Z Z^T and the log-determinant.  One workgroup (16 waves) per matrix.
-// Band storage must hold 16 (Wb + 1) diagonals per row (Wb = ceil(W/16)), zero beyond the true band.
-#define SF_WB_MAX 48
-__device__ __forceinline__ double sfw_elem(const double* __restrict__ band, int ldb, int i, int j) {
-    // element (i, j) of the symmetric band matrix (i, j global indices)
-    const int hi = max(i, j), d = hi - min(i, j);
-    return band[(int64_t)hi * ldb + d];
-}
-
-template <int NRB>
-__global__ __launch_bounds__(1024) void k_band_wide(sf_band_args a, double* __restrict__ zs_all) {
-    extern __shared__ double lds[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, lq = lane >> 4;
-    constexpr int NR = NRB * BB, LDG = NR + 1;
-    const int n = a.n, nb = n / BB, ldb = a.ldb;
-    const int Wb = (a.halfwidth + BB - 1) / BB;
-    double* LK = lds;                    // [Wb] blocks L(k, k-Wb+q), q = 0 .. Wb-1
-    double* ST = LK + Wb * BS;           // per-wave staging block
-    double* Fb = ST + 16 * BS;
-    double* G = Fb + BS;                 // [NR][LDG] Gram reduction
-    double* pv = G + NR * LDG;           // [2][16]
-    double* red = pv + 2 * BB;           // [16]
-    double* st = ST + wave * BS;
-    double* band = const_cast<double*>(a.band) + (int64_t)b * a.sband;
-    const double* __restrict__ rhs = a.rhs + (int64_t)b * a.srhs;
-    const double* __restrict__ rhs0 = a.rhs0 ? a.rhs0 + (int64_t)b * a.srhs0 : nullptr;
-    double* zs = zs_all + (int64_t)b * NR * n;  // solved right-hand-side rows [NR][n]
-    const int ncol_blocks = Wb + 1 + NRB;       // blocks of a block column: band rows k .. k+Wb, rhs rows
-    constexpr int MAXB = (SF_WB_MAX + 1 + 3 + 15) / 16;
-
-    int bad = 0;
-    double ld_acc = 0.0;
-    for (int e = tid; e < NR * LDG; e += 1024) G[e] = 0.0;
-    for (int k = 0; k < nb; ++k) {
-        const int jlo = max(k - Wb, 0);  // first block column with a non-zero L(k, j)
-        // ---- stage L(k, jlo .. k-1)
-        for (int e = tid; e < (k - jlo) * 256; e += 1024) {
-            const int q = e >> 8, r = (e >> 4) & 15, cc = e & 15;
-            LK[q * BS + r * BLD + cc] = band[(int64_t)(16 * k + r) * ldb + 16 * (k - jlo - q) + r - cc];
-        }
-        __syncthreads();
-        // ---- U
-        sf_d4 acc[MAXB];
-        int kind[MAXB], ibk[MAXB];  // kind: 0 none, 1 band row block, 2 rhs row block
-#pragma unroll
-        for (int u = 0; u < MAXB; ++u) {
-            const int t = wave + 16 * u;
-            kind[u] = 0;
-            ibk[u] = 0;
-            acc[u] = (sf_d4){0.0, 0.0, 0.0, 0.0};
-            if (t >= ncol_blocks) continue;
-            const bool isM = t <= Wb;
-            const int ib = isM ? k + t : t - Wb - 1;
-            if (isM && ib >= nb) continue;
-            kind[u] = isM ? 1 : 2;
-            ibk[u] = ib;
-            // initial value: the band block / the right-hand-side block
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = lq + 4 * r;
-                if (isM) {
-                    acc[u][r] = (t == 0) ? sfw_elem(band, ldb, 16 * k + row, 16 * k + l15)
-                                         : band[(int64_t)(16 * ib + row) * ldb + 16 * t + row - l15];
-                } else {
-                    const int rr = 16 * ib + row, col = 16 * k + l15;
-                    double v = 0.0;
-                    if (rr < a.nrhs) v = rhs0 ? (rr == 0 ? rhs0[col] : rhs[(int64_t)(rr - 1) * a.ldr + col]) : rhs[(int64_t)rr * a.ldr + col];
-                    acc[u][r] = v;
-                }
-            }
-            const int j0 = isM ? max(ib - Wb, 0) : jlo;
-            // lane (l15, lq) takes columns 4 lq .. 4 lq + 3 of its row (K permutation: slice lq of MFMA kk
-            // stands for k = 4 lq + kk in both operands)
-            auto loadA = [&](int j, double (&dst)[4]) {
-                const int jj = min(j, max(k - 1, 0));
-                if (isM) {
-                    // band row 16 ib + l15, element (., 16 jj + c): d = 16 (ib - jj) + l15 - c
-                    // the four values are contiguous in memory (descending diagonal index): two 16-byte loads
-                    // at 8-byte alignment
-                    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-                    const double* p0 = band + (int64_t)(16 * ib + l15) * ldb + 16 * (ib - jj) + l15 - 4 * lq - 3;
-                    const d2u lo = *(const d2u*)p0, hi = *(const d2u*)(p0 + 2);
-                    dst[0] = hi.y;
-                    dst[1] = hi.x;
-                    dst[2] = lo.y;
-                    dst[3] = lo.x;
-                } else {
-                    const double2* p0 = (const double2*)(zs + (int64_t)(16 * ib + l15) * n + 16 * jj + 4 * lq);
-                    const double2 lo = p0[0], hi = p0[1];
-                    dst[0] = lo.x;
-                    dst[1] = lo.y;
-                    dst[2] = hi.x;
-                    dst[3] = hi.y;
-                }
-            };
-            if (j0 >= k) continue;  // first block column: nothing to subtract (and nothing valid to prefetch)
-            double av[4][4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) loadA(j0 + d, av[d]);
-            for (int j = j0; j < k; ++j) {
-                const double* lk = LK + (j - jlo) * BS + l15 * BLD + 4 * lq;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][kk], lk[kk], acc[u], 0, 0, 1);  // neg:[1,0,0]
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) av[d][kk] = av[d + 1][kk];
-                loadA(j + 4, av[3]);
-            }
-        }
-        // ---- P: wave 0 holds the updated diagonal block in acc[0]
-        if (wave == 0) {
-            sf_d4 a0 = acc[0], f, lt;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                f[r] = (lq + 4 * r) == l15 ? 1.0 : 0.0;
-                lt[r] = 0.0;
-            }
-            double p = sfb_readlane(a0[0], 0);
-            double pkeep = 1.0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int qj = j & 3, rj = j >> 2;
-                pkeep = lane == j ? p : pkeep;
-                const double rs = sfb_rsqrt(p);
-                const bool in_q = lq == qj;
-                const double v = (in_q && l15 > j) ? a0[rj] * rs : 0.0;
-                const double g = in_q ? f[rj] * rs : 0.0;
-                if (in_q) {
-                    f[rj] = g;
-                    lt[rj] = l15 == j ? p * rs : v;  // L^T[j][i]
-                }
-                if (j + 1 < 16) {
-                    const double an = sfb_readlane(a0[(j + 1) >> 2], ((j + 1) & 3) * 16 + j + 1);
-                    const double vn = sfb_readlane(v, qj * 16 + j + 1);
-                    p = __builtin_fma(-vn, vn, an);
-                }
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, a0, 0, 0, 1);  // neg:[1,0,0]
-                f = __builtin_amdgcn_mfma_f64_16x16x4f64(v, g, f, 0, 0, 1);
-            }
-            if (lane < BB) pv[(k & 1) * BB + lane] = pkeep;
-            const unsigned long long neg = __ballot(lane < BB && !(pkeep > 0.0));
-            if (neg && !bad) bad = 16 * k + __ffsll((long long)neg);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = lq + 4 * r;
-                Fb[row * BLD + l15] = f[r];
-                if (l15 >= row) band[(int64_t)(16 * k + l15) * ldb + l15 - row] = lt[r];  // L_kk in place
-            }
-            kind[0] = 0;
-        }
-        __syncthreads();
-        if (wave == 1 && lane < BB) ld_acc += log(pv[(k & 1) * BB + lane]);
-        // ---- X
-#pragma unroll
-        for (int u = 0; u < MAXB; ++u) {
-            if (kind[u] == 0) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) st[(lq + 4 * r) * BLD + l15] = acc[u][r];
-            sf_d4 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(st[l15 * BLD + 4 * lq + kk], Fb[l15 * BLD + 4 * lq + kk], x, 0, 0, 0);
-            const int ib = ibk[u];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = lq + 4 * r;
-                if (kind[u] == 1) band[(int64_t)(16 * ib + row) * ldb + 16 * (ib - k) + row - l15] = x[r];
-                else zs[(int64_t)(16 * ib + row) * n + 16 * k + l15] = x[r];
-            }
-        }
-        __syncthreads();
-    }
-    // ---- Gram matrix of the solved right-hand sides: every wave takes a share of the block columns
-    {
-        sf_d4 gacc[NRB][NRB];
-#pragma unroll
-        for (int i = 0; i < NRB; ++i)
-#pragma unroll
-            for (int j = 0; j < NRB; ++j) gacc[i][j] = (sf_d4){0.0, 0.0, 0.0, 0.0};
-        for (int k = wave; k < nb; k += 16) {
-            double za[NRB][4];
-#pragma unroll
-            for (int i = 0; i < NRB; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) za[i][kk] = zs[(int64_t)(16 * i + l15) * n + 16 * k + 4 * lq + kk];
-#pragma unroll
-            for (int i = 0; i < NRB; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        gacc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[i][kk], za[j][kk], gacc[i][j], 0, 0, 0);
-        }
-        for (int w = 0; w < 16; ++w) {  // serial reduction into LDS (16 x NR^2 values: negligible)
-            if (wave == w) {
-#pragma unroll
-                for (int i = 0; i < NRB; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) G[(16 * i + lq + 4 * r) * LDG + 16 * j + l15] += gacc[i][j][r];
-            }
-            __syncthreads();
-        }
-    }
-    if (wave == 1 && lane < BB) red[lane] = ld_acc;
-    __syncthreads();
-    if (tid == 0) {
-        double sum = 0.0;
-        for (int i = 0; i < BB; ++i) sum += red[i];
-        a.logdet[b] = sum;
-        if (bad && a.info && a.info[b] == 0) a.info[b] = bad;
-    }
-    double* out = a.gram + (int64_t)b * a.nrhs * a.nrhs;
-    for (int e = tid; e < a.nrhs * a.nrhs; e += 1024) {
-        const int r = e / a.nrhs, c = e - r * a.nrhs;
-        out[e] = (c <= r) ? G[r * LDG + c] : G[c * LDG + r];
-    }
-}
-
-static size_t band_wide_lds_bytes(int wb, int nrb) {
-    const size_t nr = (size_t)nrb * BB;
-    return sizeof(double) * ((size_t)wb * BS + 16 * BS + BS + nr * (nr + 1) + 3 * BB);
-}
-int sf_band_wide_max_halfwidth(void) { return SF_WB_MAX * BB; }
-int sf_band_wide_storage_width(int halfwidth) { return ((halfwidth + BB - 1) / BB + 1) * BB; }
-size_t sf_band_wide_work_doubles(int n, int nrhs, int batch) {
-    return (size_t)batch * ((nrhs + BB - 1) / BB * BB) * n;
-}
-// n must be a multiple of 16 (identity-padded); `band` is overwritten by the factor; ldb >= storage width
-int sf_launch_band_wide(double* band, int n, int halfwidth, int ldb, int64_t sband, int batch, const double* rhs0,
-                        int64_t srhs0, const double* rhs, int nrhs, int ldr, int64_t srhs, double* logdet,
-                        double* gram, int* info, double* work, hipStream_t s) {
-    const int nrb = (nrhs + BB - 1) / BB, wb = (halfwidth + BB - 1) / BB;
-    if (n <= 0 || n % BB || batch <= 0 || wb > SF_WB_MAX || wb < 1 || nrb > 3 ||
-        ldb < sf_band_wide_storage_width(halfwidth) || band_wide_lds_bytes(wb, nrb) > 160 * 1024) {
-        sf_set_error("band_wide: bad arguments (n=%d halfwidth=%d ldb=%d nrhs=%d)", n, halfwidth, ldb, nrhs);
-        return SF_EINVAL;
-    }
-    sf_band_args a = {};
-    a.band = band;
-    a.sband = sband;
-    a.ldb = ldb;
-    a.halfwidth = halfwidth;
-    a.rhs = rhs;
-    a.srhs = srhs;
-    a.ldr = ldr;
-    a.nrhs = nrhs;
-    a.rhs0 = rhs0;
-    a.srhs0 = srhs0;
-    a.n = n;
-    a.logdet = logdet;
-    a.gram = gram;
-    a.info = info;
-    a.nhalf = 1;
-    static unsigned long long attr_seen = 0;  // devices whose function attributes are set
-    if (sf_first_use_on_device(&attr_seen)) {
-        SF_HIP(hipFuncSetAttribute((const void*)k_band_wide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SF_HIP(hipFuncSetAttribute((const void*)k_band_wide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SF_HIP(hipFuncSetAttribute((const void*)k_band_wide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
-    const size_t shm = band_wide_lds_bytes(wb, nrb);
-    if (nrb == 1) hipLaunchKernelGGL(k_band_wide<1>, dim3(batch), dim3(1024), shm, s, a, work);
-    else if (nrb == 2) hipLaunchKernelGGL(k_band_wide<2>, dim3(batch), dim3(1024), shm, s, a, work);
-    else hipLaunchKernelGGL(k_band_wide<3>, dim3(batch), dim3(1024), shm, s, a, work);
-    SF_LAUNCH_CHECK();
-    return SF_OK;
-}
-
 int sf_launch_woodbury(const double* gram, int nrhs, int batch, const double* logdet_band, double* logdet,
                        double* sqmah, int* info, hipStream_t s) {
     if (nrhs < 1 || nrhs > 33) {

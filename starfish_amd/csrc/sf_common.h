@@ -136,11 +136,5 @@ int sf_launch_band_forms_twisted(const double* band, int n, int halfwidth, int l
                                  hipStream_t s);
 int sf_launch_woodbury(const double* gram, int nrhs, int batch, const double* logdet_band, double* logdet,
                        double* sqmah, int* info, hipStream_t s);
-// wide bands: left-looking factorisation of the band in HBM/L2 (in place), any half-width up to
-// sf_band_wide_max_halfwidth()
-int sf_band_wide_max_halfwidth(void);
-int sf_band_wide_storage_width(int halfwidth);
-size_t sf_band_wide_work_doubles(int n, int nrhs, int batch);
-int sf_launch_band_wide(double* band, int n, int halfwidth, int ldb, int64_t sband, int batch, const double* rhs0,
-                        int64_t srhs0, const double* rhs, int nrhs, int ldr, int64_t srhs, double* logdet,
-                        double* gram, int* info, double* work, hipStream_t s);
+// wide bands (beyond the LDS window): bordered band matrices on the fused panel kernel, sf_launch_potrf_band
+#define SF_BAND_TILES_MAX_HALFWIDTH 768
