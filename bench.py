@@ -395,7 +395,7 @@ def main():
                     structured["wide_band"] = {
                         "global_ls_kms": 30.0, "band_halfwidth_px": hw_w, "ms_per_step": dtw * 1e3,
                         "value": n_local / dtw, "unit": "evals/s per GPU", "max_rel_dlnl_vs_dense_path": rel_w,
-                        "kernel": "bordered band matrix on k_diag_mfma + k_chol_panel, K loops limited to the band",
+                        "kernel": "bordered band matrix on k_diag_lds + k_chol_panel, K loops limited to the band",
                     }
 
     if rank == 0:
