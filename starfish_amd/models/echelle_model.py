@@ -14,9 +14,11 @@ from .spectrum_model import SpectrumModel
 
 
 class EchelleModel:
-    def __init__(self, emulator, data, grid_params, devices=None, name="EchelleModel", **params):
+    def __init__(self, emulator, data, grid_params, devices=None, name="EchelleModel", solver="dense", **params):
         """``params`` are shared by every order (vz, vsini, log_scale, global_cov, cheb, ...);
-        per-order overrides can be set afterwards on ``self.orders[i]``."""
+        per-order overrides can be set afterwards on ``self.orders[i]``.  ``solver`` as in
+        :class:`SpectrumModel`: "dense" (the reference's algorithm: all (order x walker) units in one batched
+        Cholesky), "auto" / "banded" (band + rank-m Woodbury per order, same value to rounding)."""
         self.name = name
         self.orders = []
         for i, order in enumerate(data):
@@ -24,7 +26,7 @@ class EchelleModel:
             dev = None if devices is None else devices[i % len(devices)]
             kw = {k: (dict(v) if isinstance(v, dict) else ([dict(x) for x in v] if k == "local_cov" else
                        (list(v) if isinstance(v, (list, tuple)) else v))) for k, v in params.items()}
-            self.orders.append(SpectrumModel(emulator, single, grid_params, device=dev, name=f"{name}[{i}]", **kw))
+            self.orders.append(SpectrumModel(emulator, single, grid_params, device=dev, name=f"{name}[{i}]", solver=solver, **kw))
 
     @classmethod
     def from_orders(cls, models, name="EchelleModel"):
@@ -86,7 +88,22 @@ class EchelleModel:
         lnl = np.full(B, -np.inf)
         info = np.zeros(B, dtype=np.int32)
         per_order = np.full((len(self.orders), B), -np.inf)
-        if finite.any():
+        structured = any(m.solver != "dense" for m in self.orders)
+        if finite.any() and structured:
+            # structure-exploiting solver: one banded call per order (a few ms each instead of a share of the dense
+            # batch; orders may need different half-widths, so they are not merged)
+            vals = np.zeros((len(self.orders), int(finite.sum())))
+            codes = np.zeros((len(self.orders), int(finite.sum())), dtype=np.int32)
+            for i, m in enumerate(self.orders):
+                dev, md, rows = m._pack(P[finite], update_caches=False)
+                out = dev.loglike(md, rows, solver=m.solver)
+                vals[i] = np.where(out["info"] == 0, out["lnl"], -np.inf)
+                codes[i] = out["info"]
+            per_order[:, finite] = vals
+            lnl[finite] = vals.sum(axis=0) + prior_lp[finite]
+            bad = codes != 0
+            info[finite] = np.where(bad.any(axis=0), codes[bad.argmax(axis=0), np.arange(codes.shape[1])], 0)
+        elif finite.any():
             packed = [m._pack(P[finite], update_caches=False) for m in self.orders]
             by_dev = {}
             for idx, (dev, md, rows) in enumerate(packed):

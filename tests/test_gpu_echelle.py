@@ -63,6 +63,24 @@ def test_echelle_orders_of_different_length_vs_oracle():
     np.testing.assert_allclose(t2[keep], total[keep], rtol=1e-12)
 
 
+def test_echelle_structured_solver_matches_the_dense_model():
+    """solver="auto" on the orders of a multi-order model: band + Woodbury per order, same sum as the one-pass dense
+    evaluation (and the same handling of a walker that leaves the grid)."""
+    sizes = [512, 300, 448]
+    orders = [synth.make_order(N=n, m=4, seed=60 + i, wave0=5000.0 * 1.02**i) for i, n in enumerate(sizes)]
+    em = synth.build_echelle(orders)
+    P = synth.shared_ball(orders[0], B=6, seed=3)
+    P[4, synth.SHARED_LABELS.index("T")] = 9000.0
+    dense, info_d, per_d = em.log_likelihood_batch(P, return_info=True, return_orders=True)
+    for m in em.orders:
+        m.solver = "auto"
+    auto, info_a, per_a = em.log_likelihood_batch(P, return_info=True, return_orders=True)
+    ok = np.arange(6) != 4
+    np.testing.assert_allclose(auto[ok], dense[ok], rtol=1e-10)
+    np.testing.assert_allclose(per_a[:, ok], per_d[:, ok], rtol=1e-10)
+    assert auto[4] == dense[4] == -np.inf and info_a[4] == info_d[4] == -1 and (info_a[ok] == 0).all()
+
+
 def test_multi_chunking_matches_single_pass():
     """A workspace cap forces the unit list through several sf_loglike_multi_batch calls: same values (to the
     rounding of a different split-K factor)."""
