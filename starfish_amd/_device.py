@@ -387,6 +387,12 @@ class DeviceOrder:
             return out
 
     def _loglike_structured(self, md, params, want_resid, max_chunk, solver):
+        return self.structured_collect(md, self.structured_enqueue(md, params, want_resid, max_chunk), solver)
+
+    def structured_enqueue(self, md, params, want_resid=False, max_chunk=None):
+        """First half of the structure-exploiting evaluation: group the walkers by covariance support and ENQUEUE the
+        banded calls on the current stream -- no host synchronisation.  :meth:`structured_collect` (after the stream
+        is done) fetches the results; callers with several orders enqueue them all first (EchelleModel)."""
         torch = _torch()
         rows = params.cpu().numpy() if torch.is_tensor(params) else np.asarray(params, dtype=np.float64)
         rows = np.atleast_2d(rows)
@@ -400,8 +406,9 @@ class DeviceOrder:
         )
         if want_resid:
             out["resid"] = np.full((B, self.n), np.nan)
-        # two groups: the cost of the wide-band kernel grows with the square of the half-width, so the
-        # walkers that fit the LDS window are not dragged along with the wide ones
+        groups = []
+        # two groups: the cost of the wide-band factorisation grows with the half-width, so the walkers that fit the
+        # LDS window are not dragged along with the wide ones
         wwin = self.banded_window_halfwidth()
         for idx in (np.nonzero(fits & (hw <= wwin))[0], np.nonzero(fits & (hw > wwin))[0]):
             if not idx.size:
@@ -421,12 +428,18 @@ class DeviceOrder:
                         md, P[lo:hi], W, lnl[lo:hi], info[lo:hi], logdet[lo:hi], sqmah[lo:hi],
                         resid[lo:hi] if want_resid else None, lsc[lo:hi],
                     )
-                host = quad.cpu().numpy()
-                for row, key in enumerate(("lnl", "logdet", "sqmah", "log_scale")):
-                    out[key][idx] = host[row]
-                out["info"][idx] = info.cpu().numpy()
-                if want_resid:
-                    out["resid"][idx] = resid.cpu().numpy()
+                groups.append((idx, quad, info, resid, P))
+        return dict(out=out, groups=groups, fits=fits, rows=rows, want_resid=want_resid, max_chunk=max_chunk)
+
+    def structured_collect(self, md, pend, solver):
+        out, rows, fits, want_resid = pend["out"], pend["rows"], pend["fits"], pend["want_resid"]
+        for idx, quad, info, resid, _ in pend["groups"]:
+            host = quad.cpu().numpy()
+            for row, key in enumerate(("lnl", "logdet", "sqmah", "log_scale")):
+                out[key][idx] = host[row]
+            out["info"][idx] = info.cpu().numpy()
+            if want_resid:
+                out["resid"][idx] = resid.cpu().numpy()
         rest = np.array([], dtype=int)
         if solver == "auto":
             # too wide for the banded kernels -> dense; an internal wait timeout (-5, cannot happen by construction) is
@@ -438,7 +451,7 @@ class DeviceOrder:
                 warnings.warn(f"banded solver: internal status -5 for {int(internal.sum())} walker(s); recomputed densely")
             rest = np.nonzero(~fits | (out["info"] == INFO_BANDWIDTH) | internal)[0]
         if rest.size:
-            dense = self.loglike(md, rows[rest], want_resid=want_resid, max_chunk=max_chunk, solver="dense")
+            dense = self.loglike(md, rows[rest], want_resid=want_resid, max_chunk=pend["max_chunk"], solver="dense")
             for key in out:
                 out[key][rest] = dense[key]
         return out

@@ -46,6 +46,15 @@ class EchelleModel:
     def __len__(self):
         return len(self.orders)
 
+    def _side_streams(self, device, n=4):
+        import torch
+
+        pools = self.__dict__.setdefault("_streams", {})
+        key = str(device)
+        if key not in pools:
+            pools[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return pools[key]
+
     @property
     def labels(self):
         return self.orders[0].labels
@@ -94,9 +103,26 @@ class EchelleModel:
             # batch; orders may need different half-widths, so they are not merged)
             vals = np.zeros((len(self.orders), int(finite.sum())))
             codes = np.zeros((len(self.orders), int(finite.sum())), dtype=np.int32)
+            # every order is enqueued before anything is waited for; the orders of a device take turns on a few
+            # side streams (a banded call of 64 walkers fills half of the chip) -- ONE synchronisation per device
+            import torch
+
+            pending, used = [], {}
             for i, m in enumerate(self.orders):
                 dev, md, rows = m._pack(P[finite], update_caches=False)
-                out = dev.loglike(md, rows, solver=m.solver)
+                if m.solver == "dense":
+                    pending.append((i, dev, md, None, rows))
+                    continue
+                pool = self._side_streams(dev.dev)
+                st = pool[len(used.setdefault(str(dev.dev), [])) % len(pool)]
+                used[str(dev.dev)].append(st)
+                st.wait_stream(torch.cuda.current_stream(dev.dev))
+                with torch.cuda.stream(st):
+                    pending.append((i, dev, md, dev.structured_enqueue(md, rows), rows))
+            for key in used:
+                torch.cuda.synchronize(torch.device(key))
+            for i, dev, md, pend, rows in pending:
+                out = dev.loglike(md, rows) if pend is None else dev.structured_collect(md, pend, self.orders[i].solver)
                 vals[i] = np.where(out["info"] == 0, out["lnl"], -np.inf)
                 codes[i] = out["info"]
             per_order[:, finite] = vals
