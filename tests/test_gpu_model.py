@@ -256,3 +256,27 @@ def test_perturbed_grid_full_size_vs_oracle(chol_sequence):
     for b in range(2):
         want = O.log_likelihood(oo, synth.vector_to_oracle_params(P[b]))
         assert close_lnl(got[b], want), (got[b], want)
+
+
+def test_full_size_properties_permutation_and_null_kernel(chol_sequence):
+    """Size-independent properties at cfg-2 size, dense and structured solver: the order of the walkers in a batch is
+    irrelevant (bit for bit: every walker is its own matrix), and a local kernel of zero amplitude changes nothing."""
+    o = synth.make_order(N=4096)
+    do = device_order(oracle_order(o))
+    plist = [synth.vector_to_oracle_params(p) for p in synth.walker_ball(o, B=6, seed=5)]
+    md, rows = pack_rows(do, plist)
+    perm = np.array([3, 0, 5, 1, 4, 2])
+    for solver in ("dense", "auto"):
+        a = do.loglike(md, rows, solver=solver)
+        b = do.loglike(md, rows[perm], solver=solver)
+        assert (a["info"] == 0).all()
+        np.testing.assert_array_equal(b["lnl"], a["lnl"][perm])
+        np.testing.assert_array_equal(b["logdet"], a["logdet"][perm])
+    # exp(-800) == 0.0: the patch of the second local kernel is filled with exact zeros
+    base = do.loglike(md, rows)
+    ghost = [dict(p, local_cov=list(p["local_cov"]) + [(float(o["wave"][2500]), -800.0, float(np.log(12.0)))]) for p in plist]
+    md2, rows2 = pack_rows(do, ghost)
+    for solver in ("dense", "auto"):
+        g = do.loglike(md2, rows2, solver=solver)
+        assert (g["info"] == 0).all()
+        np.testing.assert_allclose(g["lnl"], base["lnl"], rtol=1e-13)
