@@ -2,8 +2,7 @@
 """
 bench.py -- benchmark of the log-likelihood hot path (BASELINE.json).
 
-    python bench.py [--config cfg2|cfg3|cfg5] [--gpus N --steps K --warmup W] [--scaling weak|strong]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py [--gpus N --steps K --warmup W] [--config cfg2|cfg3|cfg5] [--scaling weak|strong]
 
 Default = the headline: BASELINE cfg 2, log-likelihood evals/sec on a synthetic 4096-pixel order, batch = 128
 walkers, fp64.  One STEP = one pass of the whole hot path (emulator query, transform chain, fused covariance
@@ -14,24 +13,33 @@ host packing by keeping the packed parameter rows on the device.
 
   cfg2   one order N = 4096, m = 8, B = 128 walkers, all 13 parameters thawed            (headline)
   cfg3   25 orders x N = 3000, B = 64 shared walkers = 1600 units through sf_loglike_multi_batch
-         (cfg 4 = the same units sharded over ranks: --gpus N --scaling strong)
+         (cfg 4 = the same units sharded order-major over ranks: --gpus N --scaling strong)
   cfg5   one order N = 16384, B = 32
 
-Multi-GPU: the units are independent, every rank evaluates its own slice on its own GPU, no data-path
-collective.  --scaling weak (default): every rank gets a full batch; --scaling strong: the batch of the config
-is split over the ranks (128/G walkers per GPU).  `value` = units of all ranks / max-over-ranks time.
+Multi-GPU: the units are independent, every rank (one process per GPU) evaluates its own
+slice on its own GPU, NO data-path collective; the process group (nccl == RCCL) only carries the barrier and
+the max-over-ranks of the timing.  `python bench.py --gpus N` with N > 1 and no RANK in the environment
+starts the N ranks itself (re-exec under torch.distributed.run on 127.0.0.1) and fails loudly when fewer than
+N GPUs are visible; launched under torch.distributed.run by somebody else it is one of the ranks.
+--scaling weak (default): every rank gets a full batch; strong: the batch of the config is split over the
+ranks (128/G walkers per GPU).  With N > 1 the line carries BOTH: the headline in the requested mode and the
+other one as the sub-object `strong` / `weak`.  `value` = units of all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line which also carries
-  roofline     -- the dominant kernel (k_chol_panel, the fused fp64 MFMA panel step of the batched Cholesky):
-                  algorithmic flops of its launches / their HIP-event time on the launch streams
-  cpu_baseline -- the CPU oracle (numpy/scipy restatement == the reference's algorithm) timed on the host cores
-                  over a bounded sample of the same walkers (N = 1 only).  The oracle is imported ONLY there.
+  roofline      -- the dominant kernel (k_chol_panel, the fused fp64 MFMA panel step of the batched Cholesky):
+                   algorithmic flops of its launches / their HIP-event time on the launch streams
+  cpu_baseline  -- the CPU oracle (numpy/scipy restatement == the reference's algorithm) timed on the host cores
+                   over a bounded sample of the same walkers (N = 1 only).  The oracle is imported ONLY there.
+  other_configs -- (default run only: N = 1, cfg 2, no overrides) short legs of cfg 3 and cfg 5
+  strong_scaling_proxy -- (same condition) cfg 2 at the per-rank batches of 2 / 4 / 8 ranks on this one GPU
 """
 import argparse
 import ctypes as C
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,19 +48,22 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (datasheet)
 HBM_PEAK_GBS = 8000.0
+N_EIG = 8
 
 CONFIGS = {
     "cfg2": dict(npix=4096, batch=128, orders=1, label="cfg2: synthetic single order"),
     "cfg3": dict(npix=3000, batch=64, orders=25, label="cfg3: multi-order model"),
     "cfg5": dict(npix=16384, batch=32, orders=1, label="cfg5: long-order stress"),
 }
+SHARE_GPU_ENV = "SF_BENCH_RANKS_SHARE_GPU"  # test hook: every rank on device 0, gloo instead of RCCL
 
 
 # ------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_pool_worker(job):
-    """cpu_baseline, pool mode: one walker through the CPU oracle in a fresh process with few BLAS threads
-    (the reference's recommended way to use many cores: one process per chain / order, docs/intro.rst:71-73)."""
-    order_args, params, blas_threads = job
+    """cpu_baseline, pool mode: `evals` walkers through the CPU oracle in a fresh process with few BLAS threads
+    (the reference's recommended way to use many cores: one process per chain / order, docs/intro.rst:71-73).
+    Returns the values and the wall-clock interval of the timed evaluations."""
+    order_args, plist, blas_threads = job
     sys.path.insert(0, ROOT)
     from threadpoolctl import threadpool_limits
 
@@ -60,15 +71,15 @@ def _cpu_pool_worker(job):
 
     with threadpool_limits(limits=blas_threads):
         oo = O.OracleOrder(*order_args)
-        O.log_likelihood(oo, params)  # first call pays the one-off set-up of the order (not timed)
-        t0 = time.perf_counter()
-        val = O.log_likelihood(oo, params)
-        return val, time.perf_counter() - t0
+        O.log_likelihood(oo, plist[0])  # first call pays the one-off set-up of the order (not timed)
+        t0 = time.time()
+        vals = [O.log_likelihood(oo, p) for p in plist]
+        return vals, t0, time.time()
 
 
-def _cpu_pool_baseline(oo_args, plist, npix, blas_threads=4, timeout=300):
-    """One walker per process on ALL host cores (cpu_count / blas_threads processes, memory permitting);
-    returns (evals/s, processes, threads/process, lnL values, wall) or None."""
+def _cpu_pool_baseline(oo_args, plist, npix, evals=3, blas_threads=4, timeout=600):
+    """`evals` walkers per process on ALL host cores (cpu_count / blas_threads processes, memory permitting).
+    The rate is MEASURED: all timed evaluations / (last end - first start) on the common wall clock."""
     import multiprocessing as mp
 
     try:
@@ -83,7 +94,9 @@ def _cpu_pool_baseline(oo_args, plist, npix, blas_threads=4, timeout=300):
     if procs < 2:
         return None
     ctx = mp.get_context("spawn")  # never fork a process that holds a HIP context
-    jobs = [(oo_args, p, blas_threads) for p in plist[:procs]]
+    # process p evaluates walkers p, p + procs, ... (wrapping around the batch)
+    idx = [[(p + k * procs) % len(plist) for k in range(evals)] for p in range(procs)]
+    jobs = [(oo_args, [plist[i] for i in ii], blas_threads) for ii in idx]
     from concurrent.futures import ProcessPoolExecutor
 
     try:
@@ -93,8 +106,11 @@ def _cpu_pool_baseline(oo_args, plist, npix, blas_threads=4, timeout=300):
             wall = time.perf_counter() - t0
     except Exception:
         return None
-    per_eval = max(r[1] for r in res)  # steady state: every process keeps evaluating at its measured rate
-    return procs / per_eval, procs, blas_threads, [r[0] for r in res], wall
+    span = max(r[2] for r in res) - min(r[1] for r in res)
+    flat_idx = [i for ii in idx for i in ii]
+    flat_val = [v for r in res for v in r[0]]
+    return dict(rate=procs * evals / span, procs=procs, blas_threads=blas_threads, evals=evals, idx=flat_idx,
+                vals=flat_val, span=span, wall=wall)
 
 
 def cpu_baseline(order, plist, lnl_gpu, args):
@@ -126,28 +142,333 @@ def cpu_baseline(order, plist, lnl_gpu, args):
         f"BLAS threads; host has {os.cpu_count()} logical CPUs)",
         "max_rel_dlnl_vs_gpu": float(rel.max()),
     }
-    pool = None if args.no_cpu_pool else _cpu_pool_baseline(oo_args, plist, len(order["wave"]))
+    pool = None if args.no_cpu_pool else _cpu_pool_baseline(oo_args, plist, len(order["wave"]), evals=args.cpu_pool_evals)
     if pool is not None:
-        rate, procs, bt, vals, wall = pool
-        relp = np.abs(lnl_gpu[: len(vals)] - np.array(vals)) / np.abs(np.array(vals))
+        vals = np.array(pool["vals"])
+        relp = np.abs(lnl_gpu[pool["idx"]] - vals) / np.abs(vals)
         assert relp.max() < 1e-8, relp
+        procs, bt, ev = pool["procs"], pool["blas_threads"], pool["evals"]
         out["single_process"] = {"value": k / tcpu, "cores": int(nthreads)}
         out["process_pool"] = {
-            "value": rate, "processes": procs, "blas_threads_per_process": bt, "cores": procs * bt,
-            "wall_s_incl_startup": wall,
-            "note": "one walker per process, rate = processes / slowest per-eval time (steady state)",
+            "value": pool["rate"], "processes": procs, "blas_threads_per_process": bt, "cores": procs * bt,
+            "evals_per_process": ev, "timed_span_s": pool["span"], "wall_s_incl_startup": pool["wall"],
+            "note": "measured aggregate: processes x evals_per_process timed evaluations / (last end - first start)",
         }
-        if rate > k / tcpu:
+        if pool["rate"] > k / tcpu:
             out.update(
-                value=rate, cores=procs * bt,
-                sample=f"{procs} walkers of the same batch (order 0), one per process ({procs} processes x {bt} BLAS "
-                f"threads = all {os.cpu_count()} logical CPUs) through oracle/sf_oracle.py; single process with "
-                f"{int(nthreads)} BLAS threads: {k / tcpu:.2f} evals/s over {k} walkers",
+                value=pool["rate"], cores=procs * bt,
+                sample=f"{procs * ev} evaluations of walkers of the same batch (order 0), {ev} per process ({procs} "
+                f"processes x {bt} BLAS threads = all {os.cpu_count()} logical CPUs) through oracle/sf_oracle.py, measured "
+                f"aggregate over {pool['span']:.1f} s; single process with {int(nthreads)} BLAS threads: {k / tcpu:.2f} "
+                f"evals/s over {k} walkers",
             )
     return out
 
 
+# ------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks ourselves, one per GPU,
+    rendezvous on 127.0.0.1; rank 0's JSON line is the only thing on stdout."""
+    import torch
+
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    share = os.environ.get(SHARE_GPU_ENV) == "1"
+    if ndev < 1 or (ndev < n and not share):
+        sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible GPUs, found {ndev} (one process per GPU; there is no "
+                         f"CPU fallback and ranks do not share a GPU unless {SHARE_GPU_ENV}=1 is set for testing)\n")
+        sys.exit(2)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 # ------------------------------------------------------------------------------------------- workloads
+class Workload:
+    """One config on this rank: the product models, the packed parameter rows on the device, `step()` = one
+    enqueue of the whole hot path over this rank's units."""
+
+    def __init__(self, cfg, rank, world, scaling, grid="loguniform", device=None):
+        import numpy as np
+        import torch
+
+        from starfish_amd import _device as D
+        from starfish_amd import parallel, synth
+
+        self.N, self.B, self.n_orders = N, B, n_orders = cfg["npix"], cfg["batch"], cfg["orders"]
+        self.units_full = B * n_orders  # units of one full batch of the config
+        self.scaling, self.world = scaling, world
+        seed = 1 + (rank if scaling == "weak" else 0)
+        if n_orders == 1:
+            order = synth.make_order(N=N)
+            if grid == "perturbed":
+                order = synth.perturb_grid(order)
+            self.model = model = synth.build_model(order, device=device)
+            # weak: every rank its own B walkers (different seeds); strong: the config's B walkers split over the ranks
+            P_all = synth.walker_ball(order, B=B, seed=seed)
+            lo, hi = (0, B) if scaling == "weak" else parallel.shard_range(B, rank, world)
+            self.P = P = P_all[lo:hi]
+            self.dev, self.md, self.rows = dev, md, rows = model._pack(P if len(P) else P_all[:1], update_caches=False)
+            self.lib, self.nf, self.device = dev.lib, dev.nf, dev.dev
+            self.n_local = n_local = hi - lo
+            self.P_dev = P_dev = D.to_dev(rows, dev.dev)
+            self.lnl = lnl = D.empty((max(n_local, 1),), dev.dev)
+            self.info = info = D.empty((max(n_local, 1),), dev.dev, torch.int32)
+
+            def step():
+                if n_local:
+                    dev.loglike_device(md, P_dev, lnl[:n_local], info[:n_local])
+
+            def results():
+                return lnl[:n_local].cpu().numpy(), info[:n_local].cpu().numpy()
+
+            self.plist = [synth.vector_to_oracle_params(p) for p in P]
+            self.order0 = order
+        else:
+            orders = synth.make_echelle(n_orders, N)
+            if grid == "perturbed":
+                orders = [synth.perturb_grid(o) for o in orders]
+            self.model = em = synth.build_echelle(orders, device=device)
+            P_all = synth.shared_ball(orders[0], B=B, seed=seed)
+            # order-major unit list (order o, walker w) -> this rank's contiguous slice keeps whole orders resident
+            lo, hi = (0, self.units_full) if scaling == "weak" else parallel.shard_range(self.units_full, rank, world)
+            segs_dev, segs_rows, md = [], [], None
+            for o, wlo, whi in parallel.order_major_slices(n_orders, B, lo, hi):
+                d_o, md, rows = em.orders[o]._pack(P_all[wlo:whi], update_caches=False)
+                segs_dev.append(d_o)
+                segs_rows.append(rows)
+            self.n_local = hi - lo
+            self.plan = plan = D.MultiPlan(segs_dev, md, segs_rows) if segs_dev else None
+            d0 = em.orders[0]._device()
+            self.lib, self.nf, self.device = d0.lib, d0.nf, d0.dev
+            self.dev = None
+
+            def step():
+                if plan is not None:
+                    plan.enqueue()
+
+            def results():
+                if plan is None:
+                    return np.zeros(0), np.zeros(0, dtype=np.int32)
+                outs = plan.collect()
+                return np.concatenate([o["lnl"] for o in outs]), np.concatenate([o["info"] for o in outs])
+
+            # CPU baseline sample: the walkers of order 0 (if this rank owns any)
+            first_rows = min(B, hi) - lo if lo < B else 0
+            self.plist = [synth.shared_to_oracle_params(orders[0], p) for p in P_all[:max(first_rows, 0)]]
+            self.order0 = orders[0]
+        self.step, self.results = step, results
+
+    @property
+    def units_total(self):
+        return self.units_full * self.world if self.scaling == "weak" else self.units_full
+
+    @property
+    def flops_eval(self):
+        N = self.N
+        return N**3 / 3 + 2 * N_EIG * N**2 + N**2
+
+    def release(self):
+        """Give the workspaces (17 - 116 GB) back before the next leg is built."""
+        import gc
+
+        import torch
+
+        if self.n_orders == 1:
+            self.dev.release_workspace()
+        else:
+            self.plan = None
+            for m in self.model.orders:
+                m._device().release_workspace()
+        self.step = self.results = self.model = self.dev = None
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def timed_leg(w, steps, warmup, prof_steps, comm, clock=None):
+    """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks.
+    Per-launch HIP events (`roofline`) are recorded during the last `prof_steps` timed steps.  `clock`: optional
+    (tensor, stream) -- one wave on its own stream samples the shader clock against the 100 MHz wall clock while
+    the timed steps run."""
+    import numpy as np
+    import torch
+
+    from starfish_amd import _device as D
+
+    lib = w.lib
+    for _ in range(warmup):
+        w.step()
+    torch.cuda.synchronize()
+    lib.sf_profile_read(None, None, None, None)
+    comm.barrier()
+    torch.cuda.synchronize()
+    if clock is not None:
+        lib.sf_debug_clock_probe(D.ptr(clock[0]), 4_000_000, C.c_void_p(clock[1].cuda_stream))
+    prof_steps = max(1, min(prof_steps, steps))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i == steps - prof_steps:
+            lib.sf_profile_enable(1)  # the event records cost ~1 % of a step (measured)
+        w.step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    lib.sf_profile_enable(0)
+    dt_max = comm.max(dt)
+    ms = (C.c_double * 6)()
+    gflops, glaunch, gcalls = C.c_double(), C.c_long(), C.c_long()
+    lib.sf_profile_read(ms, C.byref(gflops), C.byref(glaunch), C.byref(gcalls))
+    lnl_host, info_host = w.results()
+    assert (info_host == 0).all(), info_host
+    assert np.isfinite(lnl_host).all()
+    clock_mhz = None
+    if clock is not None:
+        ticks, wall = clock[0].cpu().tolist()
+        clock_mhz = 100.0 * ticks / wall if wall else None
+    gemm_s = ms[2] * 1e-3
+    achieved = gflops.value / gemm_s / 1e12 if gemm_s > 0 else 0.0
+    return dict(dt_max=dt_max, steps=steps, warmup=warmup, prof_steps=prof_steps, ms=list(ms), gflops=gflops.value,
+                launches=int(glaunch.value), achieved=achieved, clock_mhz=clock_mhz, lnl=lnl_host,
+                value=w.units_total * steps / dt_max, ms_per_step=dt_max / steps * 1e3)
+
+
+def short_summary(w, t):
+    """Sub-object of a secondary leg: value, ms_per_step, roofline.frac."""
+    return {
+        "value": t["value"], "unit": "evals/s", "ms_per_step": t["ms_per_step"], "steps": t["steps"], "warmup": t["warmup"],
+        "units_per_gpu": w.n_local, "global_batch": w.units_total,
+        "whole_path_frac_of_mfma_peak": t["value"] * w.flops_eval / 1e12 / (FP64_MFMA_PEAK_TFLOPS * w.world),
+        "roofline": {"bound": "mfma", "achieved": t["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": t["achieved"] / FP64_MFMA_PEAK_TFLOPS, "profiled_steps": t["prof_steps"]},
+        "stage_ms_per_step": {
+            k: v / t["prof_steps"]
+            for k, v in zip(["transforms", "fill", "panel_union", "potrf_stage", "solve", "panel_launches_sum"], t["ms"])
+        },
+    }
+
+
+class Comm:
+    """Barrier + max-over-ranks of a scalar: the only things the process group is used for."""
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.dist is None:
+            return float(x)
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)  # timing only: the data path has no collective
+        return float(t.item())
+
+
+def structured_leg(w, args, comm, lnl_host, custom):
+    """Secondary figure (single-order configs): the structure-exploiting solver (band + rank-m Woodbury, SURVEY.md 8
+    f-4) on the SAME walkers.  It is not the headline `value`: BASELINE's metric is the dense path."""
+    import numpy as np
+    import torch
+
+    from starfish_amd import _device as D
+
+    dev, md, rows, model, lib, n_local, N = w.dev, w.md, w.rows, w.model, w.lib, w.n_local, w.N
+    hw = int(dev.halfwidth_bound(md, rows).max())
+    if not (0 <= hw <= dev.banded_max_halfwidth()):
+        return None
+    lnl_b = D.empty((n_local,), dev.dev)
+    info_b = D.empty((n_local,), dev.dev, torch.int32)
+    ksteps = max(args.steps, 10)
+    for _ in range(2):
+        dev.loglike_banded_device(md, w.P_dev, hw, lnl_b, info_b)
+    torch.cuda.synchronize()
+    lib.sf_profile_read(None, None, None, None)
+    lib.sf_profile_enable(1)
+    comm.barrier()
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    for _ in range(ksteps):
+        dev.loglike_banded_device(md, w.P_dev, hw, lnl_b, info_b)
+    torch.cuda.synchronize()
+    comm.barrier()
+    dtb = comm.max(time.perf_counter() - tb)
+    lib.sf_profile_enable(0)
+    msb = (C.c_double * 6)()
+    lib.sf_profile_read(msb, None, None, None)
+    lb = lnl_b.cpu().numpy()
+    assert (info_b.cpu().numpy() == 0).all()
+    rel_b = float(np.max(np.abs(lb - lnl_host) / np.abs(lnl_host)))
+    assert rel_b < 1e-9, rel_b
+    # roofline of the sweep kernel: the band is read once from HBM; MFMA floor from the per-column block count
+    n16 = (N + 15) // 16 * 16
+    band_bytes = n_local * n16 * ((hw + 2) & ~1) * 8.0
+    sweep_s = msb[3] / ksteps * 1e-3
+    nbr = (hw + 15) // 16 + 1
+    mfma_per_col = nbr * (nbr + 1) / 2 + 2 * nbr + 2 * (1 + 8) + 24  # window pairs + solves + rhs rows + 16x16 potrf/inverse
+    floor_s = mfma_per_col * 64 / 4 * (n16 / 16) / 2.4e9 * max(1.0, n_local / 256.0)
+    structured = {
+        "value": n_local * w.world * ksteps / dtb, "unit": "evals/s", "ms_per_step": dtb / ksteps * 1e3,
+        "steps": ksteps, "band_halfwidth_px": hw, "max_rel_dlnl_vs_dense_path": rel_b,
+        "stage_ms_per_step": {
+            "transforms": msb[0] / ksteps, "band_fill": msb[1] / ksteps,
+            "band_cholesky_forms": msb[3] / ksteps, "woodbury_finish": msb[4] / ksteps,
+        },
+        "roofline": {
+            "kernel": "k_band_forms (LDS-window banded Cholesky + forward substitutions, one workgroup per "
+            "matrix or per half matrix)",
+            "bound": "latency (sequential 16-column chain per matrix); HBM and MFMA floors for reference",
+            "hbm": {"bytes_per_step": band_bytes, "achieved": band_bytes / sweep_s / 1e9 if sweep_s > 0 else None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": band_bytes / sweep_s / 1e9 / HBM_PEAK_GBS if sweep_s > 0 else None},
+            "mfma_floor_ms": floor_s * 1e3, "sweep_ms": sweep_s * 1e3,
+            "frac_of_mfma_floor": floor_s / sweep_s if sweep_s > 0 else None,
+        },
+        "note": "sf_loglike_banded_batch: C = band + Y^T Y never formed; same lnL to rounding; O(N W^2) flops, "
+        "so the dense MFMA roofline above does not apply to it",
+    }
+    # the same walkers with a wider global kernel (ls = 30 km/s: half-width 24 ls / dv = 361 px, beyond the LDS
+    # window): the bordered-band factorisation on the dense path's panel kernel (sf_launch_potrf_band)
+    labels = list(model.labels)
+    if "global_cov:log_ls" in labels and not custom:
+        Pw = np.array(w.P, dtype=float, copy=True)
+        Pw[:, labels.index("global_cov:log_ls")] = np.log(30.0)
+        _, md_w, rows_w = model._pack(Pw, update_caches=False)
+        hw_w = int(dev.halfwidth_bound(md_w, rows_w).max())
+        if dev.banded_window_halfwidth() < hw_w <= dev.banded_max_halfwidth():
+            Pw_dev = D.to_dev(rows_w, dev.dev)
+            dense_w = D.empty((n_local,), dev.dev)
+            dev.loglike_device(md_w, Pw_dev, dense_w, info_b)
+            for _ in range(2):
+                dev.loglike_banded_device(md_w, Pw_dev, hw_w, lnl_b, info_b)
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for _ in range(5):
+                dev.loglike_banded_device(md_w, Pw_dev, hw_w, lnl_b, info_b)
+            torch.cuda.synchronize()
+            dtw = (time.perf_counter() - tw) / 5
+            lw, dw = lnl_b.cpu().numpy(), dense_w.cpu().numpy()
+            assert (info_b.cpu().numpy() == 0).all()
+            rel_w = float(np.max(np.abs(lw - dw) / np.abs(dw)))
+            assert rel_w < 1e-9, rel_w
+            structured["wide_band"] = {
+                "global_ls_kms": 30.0, "band_halfwidth_px": hw_w, "ms_per_step": dtw * 1e3,
+                "value": n_local / dtw, "unit": "evals/s per GPU", "max_rel_dlnl_vs_dense_path": rel_w,
+                "kernel": "bordered band matrix on k_diag_lds + k_chol_panel, K loops limited to the band",
+            }
+    return structured
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,29 +484,37 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=1,
                     help="timed steps (the last ones) during which per-launch HIP events are recorded for `roofline`")
     ap.add_argument("--cpu-sample", type=int, default=8, help="walkers timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-pool-evals", type=int, default=3, help="cpu_baseline pool: timed evaluations per process")
     ap.add_argument("--no-structured", action="store_true", help="skip the banded-solver secondary figure")
     ap.add_argument("--no-cpu-pool", action="store_true", help="cpu_baseline: single-process mode only")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip other_configs (cfg 3 / cfg 5) and strong_scaling_proxy of the default run")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    in_group = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    if args.gpus > 1 and not in_group:
+        launch_ranks(args.gpus, sys.argv[1:])  # does not return
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")) if in_group else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if in_group else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if in_group else 1
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)\n")
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
-    if os.environ.get("SF_BENCH_NO_DIST"):
-        use_dist = False
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        assert dist.get_world_size() == world
-
-    from starfish_amd import _device as D
-    from starfish_amd import parallel, synth
+    share = os.environ.get(SHARE_GPU_ENV) == "1"
+    ndev = torch.cuda.device_count()
+    if world > 1 and not share and local_rank >= ndev:
+        sys.stderr.write(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible, one process per GPU)\n")
+        sys.exit(2)
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    use_dist = world > 1
 
     cfg = dict(CONFIGS[args.config])
     custom = []
@@ -194,216 +523,90 @@ def main():
         if v is not None and v != cfg[key]:
             cfg[key] = v
             custom.append(f"{key}={v}")
-    N, B, n_orders = cfg["npix"], cfg["batch"], cfg["orders"]
-    units_full = B * n_orders  # units of one full batch of the config
 
     # ---- build the model(s) through the product API and pack this rank's parameter rows
-    lib = None
-    if n_orders == 1:
-        order = synth.make_order(N=N)
-        if args.grid == "perturbed":
-            order = synth.perturb_grid(order)
-        model = synth.build_model(order)
-        # weak: every rank its own B walkers (different seeds); strong: the config's B walkers split over the ranks
-        P_all = synth.walker_ball(order, B=B, seed=1 + (rank if args.scaling == "weak" else 0))
-        lo, hi = (0, B) if args.scaling == "weak" else parallel.shard_range(B, rank, world)
-        P = P_all[lo:hi]
-        dev, md, rows = model._pack(P, update_caches=False)
-        lib = dev.lib
-        P_dev = D.to_dev(rows, dev.dev)
-        n_local = hi - lo
-        lnl = D.empty((max(n_local, 1),), dev.dev)
-        info = D.empty((max(n_local, 1),), dev.dev, torch.int32)
-        nf = dev.nf
-        device = dev.dev
-
-        def step():
-            if n_local:
-                dev.loglike_device(md, P_dev, lnl[:n_local], info[:n_local])
-
-        def results():
-            return lnl[:n_local].cpu().numpy(), info[:n_local].cpu().numpy()
-
-        plist = [synth.vector_to_oracle_params(p) for p in P]
-        order0 = order
-    else:
-        orders = synth.make_echelle(n_orders, N)
-        if args.grid == "perturbed":
-            orders = [synth.perturb_grid(o) for o in orders]
-        em = synth.build_echelle(orders)
-        P_all = synth.shared_ball(orders[0], B=B, seed=1 + (rank if args.scaling == "weak" else 0))
-        # order-major unit list (order o, walker w) -> this rank's contiguous slice keeps whole orders resident
-        lo, hi = (0, units_full) if args.scaling == "weak" else parallel.shard_range(units_full, rank, world)
-        segs_dev, segs_rows = [], []
-        for o, m in enumerate(em.orders):
-            wlo, whi = max(lo, o * B) - o * B, min(hi, (o + 1) * B) - o * B
-            if whi <= wlo:
-                continue
-            d_o, md, rows = m._pack(P_all[wlo:whi], update_caches=False)
-            segs_dev.append(d_o)
-            segs_rows.append(rows)
-        n_local = hi - lo
-        plan = D.MultiPlan(segs_dev, md, segs_rows) if segs_dev else None
-        lib = em.orders[0]._device().lib
-        nf = em.orders[0]._device().nf
-        device = em.orders[0]._device().dev
-
-        def step():
-            if plan is not None:
-                plan.enqueue()
-
-        def results():
-            if plan is None:
-                return np.zeros(0), np.zeros(0, dtype=np.int32)
-            outs = plan.collect()
-            return np.concatenate([o["lnl"] for o in outs]), np.concatenate([o["info"] for o in outs])
-
-        # CPU baseline sample: the walkers of order 0
-        first_rows = min(B, hi) - lo if lo < B else 0
-        plist = [synth.shared_to_oracle_params(orders[0], p) for p in P_all[:max(first_rows, 0)]]
-        order0 = orders[0]
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    lib.sf_profile_read(None, None, None, None)
-    barrier()
-    torch.cuda.synchronize()
-    # one wave on its own stream samples the shader clock against the 100 MHz wall clock while the timed
-    # steps run (sustained clock under this load; the datasheet peak assumes 2.4 GHz)
+    w = Workload(cfg, rank, world, args.scaling, args.grid)
+    N, B, n_orders, device, lib = w.N, w.B, w.n_orders, w.device, w.lib
     clk = torch.zeros(2, dtype=torch.int64, device=device)
     clk_stream = torch.cuda.Stream(device=device)
-    # (skipped under torch.distributed: with RCCL initialised the spinning probe kernel serialises with the
-    # main stream -- measured +40 ms on the timed region)
-    if not use_dist and not os.environ.get("SF_BENCH_NO_CLOCK"):
-        lib.sf_debug_clock_probe(D.ptr(clk), 4_000_000, C.c_void_p(clk_stream.cuda_stream))
-    # HIP events on the launch streams around every panel-kernel launch (and every stage) are recorded during the
-    # LAST `--profile-steps` of the timed steps (the event records cost ~1 % of a step, measured)
-    prof_steps = max(1, min(args.profile_steps, args.steps))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == args.steps - prof_steps:
-            lib.sf_profile_enable(1)
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    lib.sf_profile_enable(0)
-
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    clock = None if os.environ.get("SF_BENCH_NO_CLOCK") else (clk, clk_stream)
+    clock_note = "sampled by one wave on its own stream while the timed steps ran"
+    clock_mhz = None
+    dist = None
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only: the data path has no collective
-    dt_max = float(t.item())
-    units_total = units_full * world if args.scaling == "weak" else units_full
+        import torch.distributed as dist
 
-    ms = (C.c_double * 6)()
-    gflops, glaunch, gcalls = C.c_double(), C.c_long(), C.c_long()
-    lib.sf_profile_read(ms, C.byref(gflops), C.byref(glaunch), C.byref(gcalls))
-    lnl_host, info_host = results()
-    assert (info_host == 0).all(), info_host
-    assert np.isfinite(lnl_host).all()
+        # With RCCL initialised the spinning probe kernel serialises with the main stream (measured: +40 ms on the
+        # timed region), so under a process group the sustained clock is sampled BEFORE the group is created, over
+        # untimed steps of the same workload on this rank's GPU.
+        if clock is not None and w.n_local:
+            pre = timed_leg(w, 2, max(1, args.warmup), 1, Comm(None, device), clock)
+            clock_mhz = pre["clock_mhz"]
+            clock_note = "sampled on rank 0 over 2 untimed steps of the same workload before the process group was created"
+            clock = None
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if share:
+            dist.init_process_group("gloo")  # test hook: RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        assert dist.get_world_size() == world
+    comm = Comm(dist, torch.device("cpu") if share else device)
 
-    # ---- secondary figure (single-order configs): the structure-exploiting solver (band + rank-m Woodbury,
-    # SURVEY.md 8 f-4) on the SAME walkers.  It is not the headline `value`: BASELINE's metric is the dense path.
+    t = timed_leg(w, args.steps, args.warmup, args.profile_steps, comm, clock if not use_dist else None)
+    if not use_dist:
+        clock_mhz = t["clock_mhz"]
+    lnl_host = t["lnl"]
     structured = None
-    if n_orders == 1 and not args.no_structured and n_local:
-        hw = int(dev.halfwidth_bound(md, rows).max())
-        if 0 <= hw <= dev.banded_max_halfwidth():
-            lnl_b = D.empty((n_local,), dev.dev)
-            info_b = D.empty((n_local,), dev.dev, torch.int32)
-            ksteps = max(args.steps, 10)
-            for _ in range(2):
-                dev.loglike_banded_device(md, P_dev, hw, lnl_b, info_b)
-            torch.cuda.synchronize()
-            lib.sf_profile_read(None, None, None, None)
-            lib.sf_profile_enable(1)
-            barrier()
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            for _ in range(ksteps):
-                dev.loglike_banded_device(md, P_dev, hw, lnl_b, info_b)
-            torch.cuda.synchronize()
-            barrier()
-            dtb = time.perf_counter() - tb
-            lib.sf_profile_enable(0)
-            tt = torch.tensor([dtb], dtype=torch.float64, device=dev.dev)
-            if use_dist:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtb = float(tt.item())
-            msb = (C.c_double * 6)()
-            lib.sf_profile_read(msb, None, None, None)
-            lb = lnl_b.cpu().numpy()
-            assert (info_b.cpu().numpy() == 0).all()
-            rel_b = float(np.max(np.abs(lb - lnl_host) / np.abs(lnl_host)))
-            assert rel_b < 1e-9, rel_b
-            # roofline of the sweep kernel: the band is read once from HBM; MFMA floor from the per-column block count
-            n16 = (N + 15) // 16 * 16
-            band_bytes = n_local * n16 * ((hw + 2) & ~1) * 8.0
-            sweep_s = msb[3] / ksteps * 1e-3
-            nbr = (hw + 15) // 16 + 1
-            mfma_per_col = nbr * (nbr + 1) / 2 + 2 * nbr + 2 * (1 + 8) + 24  # window pairs + solves + rhs rows + 16x16 potrf/inverse
-            floor_s = mfma_per_col * 64 / 4 * (n16 / 16) / 2.4e9 * max(1.0, n_local / 256.0)
-            structured = {
-                "value": n_local * world * ksteps / dtb, "unit": "evals/s", "ms_per_step": dtb / ksteps * 1e3,
-                "steps": ksteps, "band_halfwidth_px": hw, "max_rel_dlnl_vs_dense_path": rel_b,
-                "stage_ms_per_step": {
-                    "transforms": msb[0] / ksteps, "band_fill": msb[1] / ksteps,
-                    "band_cholesky_forms": msb[3] / ksteps, "woodbury_finish": msb[4] / ksteps,
-                },
-                "roofline": {
-                    "kernel": "k_band_forms (LDS-window banded Cholesky + forward substitutions, one workgroup per "
-                    "matrix or per half matrix)",
-                    "bound": "latency (sequential 16-column chain per matrix); HBM and MFMA floors for reference",
-                    "hbm": {"bytes_per_step": band_bytes, "achieved": band_bytes / sweep_s / 1e9 if sweep_s > 0 else None,
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": band_bytes / sweep_s / 1e9 / HBM_PEAK_GBS if sweep_s > 0 else None},
-                    "mfma_floor_ms": floor_s * 1e3, "sweep_ms": sweep_s * 1e3,
-                    "frac_of_mfma_floor": floor_s / sweep_s if sweep_s > 0 else None,
-                },
-                "note": "sf_loglike_banded_batch: C = band + Y^T Y never formed; same lnL to rounding; O(N W^2) flops, "
-                "so the dense MFMA roofline above does not apply to it",
-            }
+    if n_orders == 1 and not args.no_structured and w.n_local:
+        structured = structured_leg(w, args, comm, lnl_host, custom)
 
-            # the same walkers with a wider global kernel (ls = 30 km/s: half-width 24 ls / dv = 361 px, beyond the LDS
-            # window): the bordered-band factorisation on the dense path's panel kernel (sf_launch_potrf_band)
-            labels = list(model.labels)
-            if "global_cov:log_ls" in labels and not custom:
-                Pw = np.array(P, dtype=float, copy=True)
-                Pw[:, labels.index("global_cov:log_ls")] = np.log(30.0)
-                _, md_w, rows_w = model._pack(Pw, update_caches=False)
-                hw_w = int(dev.halfwidth_bound(md_w, rows_w).max())
-                if dev.banded_window_halfwidth() < hw_w <= dev.banded_max_halfwidth():
-                    Pw_dev = D.to_dev(rows_w, dev.dev)
-                    dense_w = D.empty((n_local,), dev.dev)
-                    dev.loglike_device(md_w, Pw_dev, dense_w, info_b)
-                    for _ in range(2):
-                        dev.loglike_banded_device(md_w, Pw_dev, hw_w, lnl_b, info_b)
-                    torch.cuda.synchronize()
-                    tw = time.perf_counter()
-                    for _ in range(5):
-                        dev.loglike_banded_device(md_w, Pw_dev, hw_w, lnl_b, info_b)
-                    torch.cuda.synchronize()
-                    dtw = (time.perf_counter() - tw) / 5
-                    lw, dw = lnl_b.cpu().numpy(), dense_w.cpu().numpy()
-                    assert (info_b.cpu().numpy() == 0).all()
-                    rel_w = float(np.max(np.abs(lw - dw) / np.abs(dw)))
-                    assert rel_w < 1e-9, rel_w
-                    structured["wide_band"] = {
-                        "global_ls_kms": 30.0, "band_halfwidth_px": hw_w, "ms_per_step": dtw * 1e3,
-                        "value": n_local / dtw, "unit": "evals/s per GPU", "max_rel_dlnl_vs_dense_path": rel_w,
-                        "kernel": "bordered band matrix on k_diag_lds + k_chol_panel, K loops limited to the band",
-                    }
+    # ---- N > 1: the other scaling mode as a sub-object (SURVEY.md 8e split: units of ONE batch over the ranks)
+    other_mode, other = None, None
+    if use_dist:
+        other_mode = "strong" if args.scaling == "weak" else "weak"
+        plist0, order0 = w.plist, w.order0
+        w.release()
+        w2 = Workload(cfg, rank, world, other_mode, args.grid)
+        t2 = timed_leg(w2, args.steps, args.warmup, args.profile_steps, comm)
+        other = short_summary(w2, t2)
+        other["scaling"] = other_mode
+        other["n_gpus"] = world
+        w2.release()
+    default_run = (world == 1 and args.config == "cfg2" and not custom and args.grid == "loguniform"
+                   and not args.no_extra_legs)
+    extra, proxy = None, None
+    if default_run:
+        plist0, order0 = w.plist, w.order0
+        base_ms_per_eval = t["ms_per_step"] / w.n_local
+        w.release()
+        # strong-scaling proxy on the one GPU: the per-rank batch of 2 / 4 / 8 ranks (128/G walkers)
+        proxy = [{"ranks_equivalent": 1, "batch": B, "value": t["value"], "ms_per_step": t["ms_per_step"],
+                  "per_eval_efficiency_vs_full_batch": 1.0}]
+        for g in (2, 4, 8):
+            c = dict(cfg, batch=B // g)
+            wp = Workload(c, 0, 1, "weak")
+            tp = timed_leg(wp, 5, 2, 1, comm)
+            proxy.append({"ranks_equivalent": g, "batch": B // g, "value": tp["value"], "ms_per_step": tp["ms_per_step"],
+                          "per_eval_efficiency_vs_full_batch": base_ms_per_eval / (tp["ms_per_step"] / wp.n_local),
+                          "panel_frac_of_peak": tp["achieved"] / FP64_MFMA_PEAK_TFLOPS})
+            wp.release()
+        extra = {}
+        for name, steps_x in (("cfg3", 3), ("cfg5", 3)):
+            wx = Workload(CONFIGS[name], 0, 1, "weak")
+            tx = timed_leg(wx, steps_x, 1, 1, comm)
+            extra[name] = short_summary(wx, tx)
+            extra[name]["workload"] = CONFIGS[name]["label"] + f": {wx.n_orders} order(s) x N_pix={wx.N}, batch={wx.B}"
+            extra[name]["ceiling_evals_per_s"] = FP64_MFMA_PEAK_TFLOPS * 1e12 / wx.flops_eval
+            wx.release()
+    elif not use_dist:
+        plist0, order0 = w.plist, w.order0
 
     if rank == 0:
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 as the
         # micro-arch guide prescribes for gfx950, + WRITE_SIZE) summarised under profiles/ by
         # tools/summarize_profile.py; bench.py cannot collect counters itself.
         traffic, traffic_src = None, None
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r02_*{args.config}*_pmc_summary.json")))[-1:]:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0[0-9]_*{args.config}*_pmc_summary.json")))[-1:]:
             if not custom and args.grid == "loguniform":
                 with open(f) as fh:
                     summ = json.load(fh)
@@ -411,31 +614,28 @@ def main():
                 if key:
                     traffic = summ[key]["hbm_bytes_per_launch"]
                     traffic_src = os.path.relpath(f, ROOT)
-        ticks, wall = clk.cpu().tolist()
-        clock_mhz = 100.0 * ticks / wall if wall else 0.0
-        gemm_s = ms[2] * 1e-3
-        achieved = gflops.value / gemm_s / 1e12 if gemm_s > 0 else 0.0
-        flops_eval = N**3 / 3 + 2 * 8 * N**2 + N**2
+        ms, prof_steps, achieved = t["ms"], t["prof_steps"], t["achieved"]
         label = cfg["label"] + (" [custom: " + ", ".join(custom) + "]" if custom else "")
+        per = " per GPU" if args.scaling == "weak" else " in total"
         if n_orders == 1:
-            workload = (f"{label} N_pix={N}, 8 eigenspectra, M=27, N_f={nf}, 1 global + 1 local kernel, all 13 "
-                        f"parameters thawed, batch={B} walkers" + (" per GPU" if args.scaling == "weak" else " in total"))
+            workload = (f"{label} N_pix={N}, 8 eigenspectra, M=27, N_f={w.nf}, 1 global + 1 local kernel, all 13 "
+                        f"parameters thawed, batch={B} walkers" + per)
             metric = f"log-likelihood evals/sec, {N}-pixel order, batch={B} walkers"
         else:
-            workload = (f"{label}: {n_orders} echelle orders x N_pix={N}, 8 eigenspectra, M=27, N_f={nf}, shared walkers "
-                        f"batch={B} (10 thawed parameters, every order its own local kernel) = {units_full} (order x walker) "
-                        "units" + (" per GPU" if args.scaling == "weak" else " in total") + ", one sf_loglike_multi_batch pass")
+            workload = (f"{label}: {n_orders} echelle orders x N_pix={N}, 8 eigenspectra, M=27, N_f={w.nf}, shared walkers "
+                        f"batch={B} (10 thawed parameters, every order its own local kernel) = {w.units_full} (order x walker) "
+                        "units" + per + ", one sf_loglike_multi_batch pass")
             metric = f"single-order log-likelihood evals/sec (order x walker units), {n_orders} orders x {N} pixels, batch={B} walkers"
         if args.grid == "perturbed":
             workload += "; NON log-uniform wavelength grid (K_global per entry)"
         out = {
             "metric": metric,
-            "value": units_total * args.steps / dt_max,
+            "value": t["value"],
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
+            "ms_per_step": t["ms_per_step"],
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -443,12 +643,14 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": workload,
-                "global_batch": units_total,
-                "units_per_gpu": n_local,
-                "parallelism": f"(order x walker) units sharded x{world}, no collective",
+                "global_batch": w.units_total,
+                "units_per_gpu": w.n_local,
+                "parallelism": f"(order x walker) units sharded x{world}, one process per GPU, no data-path collective"
+                + (" (process group: " + ("gloo, ranks share device 0 [test hook]" if share else "nccl/RCCL") + ", barrier + timing max only)"
+                   if use_dist else ""),
             },
-            "whole_path_tflops": units_total * args.steps * flops_eval / dt_max / 1e12,
-            "whole_path_frac_of_mfma_peak": units_total * args.steps * flops_eval / dt_max / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+            "whole_path_tflops": t["value"] * w.flops_eval / 1e12,
+            "whole_path_frac_of_mfma_peak": t["value"] * w.flops_eval / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
             "roofline": {
                 "kernel": "k_chol_panel (fused v_mfma_f64_16x16x4_f64 panel step of the batched Cholesky: long-K update "
                 "+ triangular solve + diagonal-tile update)",
@@ -458,30 +660,40 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                 "sustained_clock_mhz": clock_mhz or None,
+                "sustained_clock_note": clock_note if clock_mhz else None,
                 "peak_at_sustained_clock": FP64_MFMA_PEAK_TFLOPS * clock_mhz / 2400.0 if clock_mhz else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "note": "the panel launches run on several streams (lookahead chain, slab groups) and overlap: `achieved` "
-                "divides by the UNION of the launch intervals (HIP events, common origin, recorded during the last "
+                "note": "rank 0's GPU; the panel launches run on several streams (lookahead chain, slab groups) and overlap: "
+                "`achieved` divides by the UNION of the launch intervals (HIP events, common origin, recorded during the last "
                 "`profiled_steps` of the timed steps); avg_launch_ms is the plain mean launch duration (what rocprofv3 "
                 "--stats reports)",
                 "profiled_steps": prof_steps,
-                "launches": int(glaunch.value),
-                "avg_launch_ms": ms[5] / max(1, glaunch.value),
-                "achieved_by_sum_of_launch_durations": gflops.value / (ms[5] * 1e-3) / 1e12 if ms[5] > 0 else None,
-                "algorithmic_flops_per_launch": gflops.value / max(1, glaunch.value),
+                "launches": t["launches"],
+                "avg_launch_ms": ms[5] / max(1, t["launches"]),
+                "achieved_by_sum_of_launch_durations": t["gflops"] / (ms[5] * 1e-3) / 1e12 if ms[5] > 0 else None,
+                "algorithmic_flops_per_launch": t["gflops"] / max(1, t["launches"]),
             },
             "stage_ms_per_step": {
                 k: v / prof_steps
                 for k, v in zip(["transforms", "fill", "panel_union", "potrf_stage", "solve", "panel_launches_sum"], ms)
             },
-            "potrf_stage_tflops": n_local * prof_steps * (N**3 / 3) / (ms[3] * 1e-3) / 1e12 if ms[3] > 0 else None,
+            "potrf_stage_tflops": w.n_local * prof_steps * (N**3 / 3) / (ms[3] * 1e-3) / 1e12 if ms[3] > 0 else None,
             "structured_solver": structured,
         }
-        if world == 1 and args.cpu_sample > 0 and plist:
-            out["cpu_baseline"] = cpu_baseline(order0, plist, lnl_host, args)
-        print(json.dumps(out))
+        if other is not None:
+            out[other_mode] = other
+        if proxy is not None:
+            out["strong_scaling_proxy"] = {
+                "note": "1-GPU proxy of the strong split (SURVEY.md 8e: 128/G walkers per GPU): cfg 2 at the per-rank batch "
+                "of G ranks, 5 timed steps each", "rows": proxy}
+        if extra is not None:
+            out["other_configs"] = extra
+        if world == 1 and args.cpu_sample > 0 and plist0:
+            out["cpu_baseline"] = cpu_baseline(order0, plist0, lnl_host, args)
+        print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -100,6 +100,11 @@ def factor_v11(v11, w_hat):
     return np.ascontiguousarray(linv), np.ascontiguousarray(alpha)
 
 
+def model_desc_key(md):
+    """The fields of a ModelDesc as a hashable tuple (two orders may share a multi-order call only if equal)."""
+    return tuple(int(getattr(md, name)) for name, _ in md._fields_)
+
+
 class MultiPlan:
     """Device-resident state of a repeated multi-order evaluation (sf_loglike_multi_batch): parameter rows,
     outputs and workspace are allocated once; :meth:`enqueue` only launches.  ``orders`` are
@@ -114,6 +119,11 @@ class MultiPlan:
         self.dev = orders[0].dev
         if any(o.dev != self.dev for o in orders):
             raise ValueError("multi-order call: all orders must live on the same device")
+        stride = orders[0].param_stride(md)
+        for o, r in zip(orders, rows_list):
+            if o.param_stride(md) != stride or int(r.shape[-1]) != stride:
+                raise ValueError(f"multi-order call: parameter rows of {int(r.shape[-1])} doubles do not match the "
+                                 f"descriptor's stride {stride} (orders with different descriptors need separate calls)")
         self.sizes = [int(np.atleast_2d(r).shape[0]) if not torch.is_tensor(r) else int(r.shape[0]) for r in rows_list]
         U = sum(self.sizes)
         with torch.cuda.device(self.dev):

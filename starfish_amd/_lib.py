@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstarfish_amd.so")
+# SF_LIB_PATH: development hook for tools/ -- load another build of the SAME library (the `make TUNING=1` variant with
+# the environment tuning switches compiled in).  The release library itself reads no environment variable.
+LIB_PATH = os.environ.get("SF_LIB_PATH") or os.path.join(_HERE, "libstarfish_amd.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)

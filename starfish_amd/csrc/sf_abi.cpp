@@ -1064,7 +1064,7 @@ static int multi_layout(const sf_segment* segs, int nseg, const sf_model_desc* m
 // factorisation's launches full) and the rest as the second -- only the first chunk's fills are exposed, the others
 // run behind the first factorisation.  (Equal chunks: 1, 2, 3, 4 of them gave 283.1, 282.1, 282.7, 283.9 ms at cfg 3.)
 static int multi_first_units(int U) {
-    static const int first = getenv("SF_MULTI_FIRST") ? std::max(1, atoi(getenv("SF_MULTI_FIRST"))) : 256;  // tuning aid
+    static const int first = std::max(1, SF_TUNE_INT("SF_MULTI_FIRST", 256));  // tuning aid
     return std::min(U, first);
 }
 static int multi_chunk_cap(int U, int bmax) { return std::min(U, std::max(U - multi_first_units(U), multi_first_units(U) + bmax)); }
@@ -1103,7 +1103,7 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
     sf_exec* ex = &c0->exec;
     rc = sf_exec_prepare(ex);
     if (rc) return rc;
-    static const bool no_pipe = getenv("SF_MULTI_NO_PIPELINE") != nullptr;  // tuning aid
+    static const bool no_pipe = SF_TUNE_FLAG("SF_MULTI_NO_PIPELINE");  // tuning aid
     hipStream_t sp = no_pipe ? s : ex->aux;
     const int first_units = multi_first_units(U);
     if (sp != s) {
@@ -1271,7 +1271,7 @@ extern "C" int sf_loglike_banded_batch(sf_ctx* c, const sf_model_desc* mdl, int 
         f.add_jitter = 1;
         f.npad = (c->n + 15) / 16 * 16;
         if (bw.tiles) {  // straight into the 128 x 128 tiles of the bordered band matrix
-            static const bool poison = getenv("SF_BAND_TILES_POISON") != nullptr;  // test aid: NaN wherever a tile is read before it is written
+            static const bool poison = SF_TUNE_FLAG("SF_BAND_TILES_POISON");  // test aid: NaN wherever a tile is read before it is written
             if (poison) SF_HIP(hipMemsetAsync(bw.tiles, 0xff, sizeof(double) * sf_band_tiles_doubles(c->npad, B), sf));
             f.npad = c->npad;
             const int lda_t = sf_band_tiles_lda(c->npad);

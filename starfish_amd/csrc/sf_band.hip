@@ -689,16 +689,17 @@ int sf_launch_band_forms(const double* band, int n, int halfwidth, int ldb, int6
 static int launch_forms_kernel(const sf_band_args& a, int nrb, int nblocks, hipStream_t s) {
     const int nbr = a.nbr;
     const size_t shm = band_lds_bytes(nbr, nrb);
-    static unsigned long long attr_seen = 0;  // devices whose function attributes are set
-    if (sf_first_use_on_device(&attr_seen)) {
+    static sf_dev_once attr_once;  // devices whose function attributes are set
+    SF_CHECK(sf_once_per_device(&attr_once, []() -> int {
         SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SF_HIP(hipFuncSetAttribute((const void*)k_band_forms<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+        return SF_OK;
+    }));
     // waves 4.. prefetch the band rows in groups of 256 threads (one 16 x 16 block per group and
     // register): enough groups for SFB_PF registers to cover the nbr blocks of a block row
     int nwaves = nbr <= SFB_PF ? 8 : nbr <= 2 * SFB_PF ? 12 : 16;
-    static const int force_waves = getenv("SF_BAND_WAVES") ? atoi(getenv("SF_BAND_WAVES")) : 0;
+    static const int force_waves = SF_TUNE_INT("SF_BAND_WAVES", 0);
     if (force_waves) nwaves = force_waves;
     if (nwaves < 8 || nwaves > 16 || (nwaves & 3) || ((nwaves - 4) / 4) * SFB_PF < nbr ||
         nwaves * 64 < (nbr - 1 + nrb) * BB) {
@@ -732,7 +733,7 @@ bool sf_band_twisted_applicable(int n, int halfwidth, int batch) {
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             ncu = 1;
     }
-    static const bool off = getenv("SF_BAND_NO_TWIST") != nullptr;
+    static const bool off = SF_TUNE_FLAG("SF_BAND_NO_TWIST");
     const int nbr = band_nbr(halfwidth), nblk = (n + BB - 1) / BB;
     if (off || n % BB != 0 || nblk < 6 * nbr) return false;
     // One workgroup occupies a CU for the whole sweep, so the launch takes ceil(workgroups / CUs) rounds.

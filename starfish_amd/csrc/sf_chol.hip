@@ -21,6 +21,11 @@
 
 #include "sf_common.h"
 
+#ifdef SF_TUNING
+#define SF_PANEL_SKIPS(g, bit) ((g).skip & (bit))  // phase switched off (wrong results, timing only)
+#else
+#define SF_PANEL_SKIPS(g, bit) (false)
+#endif
 #define GT 128  // C tile edge of the MFMA kernel
 #define GK 16   // K slab staged in LDS per step
 #ifndef GLD
@@ -597,12 +602,12 @@ static int launch_gemm(sf_gemm_args g, int batch, bool neg, double flops, hipStr
         sf_set_error("gemm grid too large");
         return SF_EINVAL;
     }
-    static const bool no_syrk = getenv("SF_NO_SYRK") != nullptr;
+    static const bool no_syrk = SF_TUNE_FLAG("SF_NO_SYRK");
     g.no_syrk = no_syrk;
     void* tok;
     sf_prof_gemm_begin(s, flops, &tok);
-    static const bool big = getenv("SF_GEMM_1024") != nullptr;  // tuning aid: 16 waves of 32 x 32
-    static const bool small = getenv("SF_GEMM_256") != nullptr;  // tuning aid: 4 waves of 64 x 64
+    static const bool big = SF_TUNE_FLAG("SF_GEMM_1024");  // tuning aid: 16 waves of 32 x 32
+    static const bool small = SF_TUNE_FLAG("SF_GEMM_256");  // tuning aid: 4 waves of 64 x 64
     if (small) {
         if (g.rhs)
             hipLaunchKernelGGL((k_gemm_nt<true, true, 256>), dim3((unsigned)nblk), dim3(256), 0, s, g);
@@ -1047,13 +1052,15 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
 #define SF_DIAG_LDS_BYTES ((73 * DBS + 128) * sizeof(double))
 static int sf_launch_diag128(double* T, int64_t sT, int pw, int* info, int info_off, double* rhs, int ldr, double* Cdiag,
                              int ldc, int64_t sC, double* Wt, int64_t sW, int batch, hipStream_t s) {
-    static const bool scratch = getenv("SF_DIAG_SCRATCH") != nullptr;  // tuning aid: the L2-resident k_diag_mfma<512>
+    static const bool scratch = SF_TUNE_FLAG("SF_DIAG_SCRATCH");  // tuning aid: the L2-resident k_diag_mfma<512>
     if (scratch) {
         hipLaunchKernelGGL(k_diag_mfma<512>, dim3(batch), dim3(512), 0, s, T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc, sC, Wt, sW);
     } else {
-        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
-        if (sf_first_use_on_device(&attr_seen))
+        static sf_dev_once attr_once;  // devices whose function attributes are set
+        SF_CHECK(sf_once_per_device(&attr_once, []() -> int {
             SF_HIP(hipFuncSetAttribute((const void*)k_diag_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            return SF_OK;
+        }));
         hipLaunchKernelGGL(k_diag_lds, dim3(batch), dim3(512), SF_DIAG_LDS_BYTES, s, T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc,
                            sC, Wt, sW);
     }
@@ -1083,7 +1090,9 @@ struct sf_panel_args {
     int k0, pw;       // panel columns [k0, k0 + pw), pw in {0, 64, 128}
     int row0, nslab;  // nslab slabs of 128 rows, the first at row0 (multiple of 128); the last one may be shorter
     int slab_step;    // distance between consecutive slabs of this launch, in slabs (slab groups are interleaved)
-    int skip;         // tuning aid (wrong results, timing only): 1 no solve, 2 no rank-pw update, 4 no main loop
+#ifdef SF_TUNING
+    int skip;         // tuning builds only (wrong results, timing only): 1 no solve, 2 no rank-pw update, 4 no main loop
+#endif
     // split-K for launches that cannot fill the chip (late panels, small batches): mode 1 = ksplit workgroups per
     // slab each accumulate kchunk K-slabs and park their 128 x 128 partial sum in `part`; mode 2 = one workgroup
     // per slab adds the partial sums in fixed order (deterministic) and runs steps 2-4; mode 0 = everything at once
@@ -1207,7 +1216,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             }
         };
         auto gwait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-        const int nk_all = (g.skip & 4) ? 0 : k0 / GK;
+        const int nk_all = SF_PANEL_SKIPS(g, 4) ? 0 : k0 / GK;
         // band: the K loop starts at the first column where both operands can be non-zero (a band slab's own rows;
         // for the dense border rows the panel's rows decide -- what lies left of that was never even written)
         const int klo = g.kband ? min(max((row0 < g.nband ? row0 : k0) - g.kband, 0) / GK, nk_all) : 0;
@@ -1341,7 +1350,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         }
 
         // ---------------------------------------------------------------- 2: L = T W through LDS
-        const int nsb = (g.skip & 1) ? 0 : pw >> 4;  // 16-column blocks of the panel (4 or 8)
+        const int nsb = SF_PANEL_SKIPS(g, 1) ? 0 : pw >> 4;  // 16-column blocks of the panel (4 or 8)
         const double* Wp[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p)
@@ -1459,7 +1468,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             }
         }
         const int nstore = h == 0 ? 5 : 4;
-        const int nk2 = (g.skip & 2) ? 0 : pw / GK;
+        const int nk2 = SF_PANEL_SKIPS(g, 2) ? 0 : pw / GK;
         const int lr = tid >> 3, lc = (tid & 7) * 2;
         const double* Lp[2];
 #pragma unroll
@@ -1536,7 +1545,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
 #define SF_CHIP_WGS 512
 #define SF_SPLIT_MAX 8
 static int sf_split_policy(long long wgs, int nk) {
-    static const int force = getenv("SF_CHOL_SPLIT") ? atoi(getenv("SF_CHOL_SPLIT")) : -1;  // tuning aid
+    static const int force = SF_TUNE_INT("SF_CHOL_SPLIT", -1);  // tuning aid
     int S = 1;
     while (2 * S <= SF_SPLIT_MAX && wgs * 2 * S <= SF_CHIP_WGS && nk / (2 * S) >= 8) S *= 2;
     if (force >= 1) {
@@ -1593,8 +1602,8 @@ static int sf_launch_potrf_v1(double* A, int n, int lda, int64_t stride, int bat
     SF_TRY(sf_exec_prepare(ex));
     hipStream_t c = ex->side;  // side ("critical chain") stream
     auto next_event = [&](hipEvent_t* e) { return sf_exec_event(ex, e); };
-    static const bool no_lookahead = getenv("SF_NO_LOOKAHEAD") != nullptr;  // tuning aid: single stream
-    static const int rlazy = getenv("SF_RLAZY") ? atoi(getenv("SF_RLAZY")) : 1;  // tuning aid; measured: no gain for 2, 4, 8
+    static const bool no_lookahead = SF_TUNE_FLAG("SF_NO_LOOKAHEAD");  // tuning aid: single stream
+    static const int rlazy = SF_TUNE_INT("SF_RLAZY", 1);  // tuning aid; measured: no gain for 2, 4, 8
     if (no_lookahead) c = s;
     hipEvent_t e_fork, e_gt_prev = nullptr;
     SF_TRY(next_event(&e_fork));
@@ -1676,7 +1685,7 @@ static int sf_launch_potrf_v1(double* A, int n, int lda, int64_t stride, int bat
             SF_HIP(hipEventRecord(e_ur, s));
         }
         // ---- D + F on the side stream (T rows [0, pw) already hold the fully updated diagonal block)
-        static const bool leaf_diag = getenv("SF_LEAF_DIAG") != nullptr;  // tuning aid: the 13-launch chain
+        static const bool leaf_diag = SF_TUNE_FLAG("SF_LEAF_DIAG");  // tuning aid: the 13-launch chain
         if (!leaf_diag) {
             hipLaunchKernelGGL(k_diag_mfma<1024>, dim3(batch), dim3(1024), 0, c, T, sT, pw, info, k0,
                                rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW);
@@ -1793,8 +1802,8 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
     const int64_t sW = (int64_t)SF_NB * SF_LDT + SF_TSKEW;
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
     SF_TRY(sf_exec_prepare(ex));
-    static const bool no_lookahead = getenv("SF_NO_LOOKAHEAD") != nullptr;
-    static const int ngroups_env = getenv("SF_CHOL_GROUPS") ? atoi(getenv("SF_CHOL_GROUPS")) : 2;
+    static const bool no_lookahead = SF_TUNE_FLAG("SF_NO_LOOKAHEAD");
+    static const int ngroups_env = SF_TUNE_INT("SF_CHOL_GROUPS", 2);
     const int G = no_lookahead ? 1 : (ngroups_env < 1 ? 1 : (ngroups_env > SF_EXEC_GROUPS ? SF_EXEC_GROUPS : ngroups_env));
     hipStream_t c = no_lookahead ? s : ex->side;
     hipStream_t gs[SF_EXEC_GROUPS];
@@ -1819,8 +1828,10 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
         g.row0 = row0;
         g.nslab = nslab;
         g.slab_step = step;
-        static const int skip = getenv("SF_PANEL_SKIP") ? atoi(getenv("SF_PANEL_SKIP")) : 0;
+#ifdef SF_TUNING
+        static const int skip = SF_TUNE_INT("SF_PANEL_SKIP", 0);
         g.skip = skip;
+#endif
         g.Wt = Wt;
         g.sW = sW;
         g.rhs = rhs;
@@ -2059,7 +2070,7 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     // are bound by the number of sequential long-K steps, and the unfused sequence has half as many (256-column
     // panels): measured at N = 4096, B = 16: 10.3 vs 11.2 ms; B = 24: 13.3 vs 13.7; B = 32: 16.6 vs 16.3; B = 64: 29.5 vs 28.3;
     // B = 128: 55.3 vs 50.4.
-    static const char* force = getenv("SF_CHOL_UNFUSED");  // tuning aid: "1" always unfused, "0" always fused
+    static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");  // tuning aid: "1" always unfused, "0" always fused
     const int sel = g_chol_sequence.load();                 // sf_debug_cholesky_sequence(): tests drive both
     const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] != '0' : batch < 28);
     if (!ex) ex = sf_exec_thread_local();
@@ -2076,11 +2087,12 @@ int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int 
     const size_t fixed = sizeof(double) * (SF_LEAF * 65 + SF_LEAF + 8);
     const size_t with_z = fixed + sizeof(double) * (size_t)n;
     if (with_z <= 160 * 1024) {
-        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
-        if (sf_first_use_on_device(&attr_seen)) {
+        static sf_dev_once attr_once;  // devices whose function attributes are set
+        SF_CHECK(sf_once_per_device(&attr_once, []() -> int {
             SF_HIP(hipFuncSetAttribute((const void*)k_trsv_logdet<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            return SF_OK;
+        }));
         hipLaunchKernelGGL(k_trsv_logdet<false>, dim3(batch), dim3(256), with_z, s, L, n, lda, stride, R,
                            ldr, (double*)nullptr, logdet, sqmah);
     } else {

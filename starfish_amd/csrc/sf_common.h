@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include "../../include/starfish_amd.h"
 
 #define SF_LEAF 64        // Cholesky leaf block (potrf / trsm granularity); matrices padded to it
@@ -33,16 +36,43 @@ void sf_set_error(const char* fmt, ...);
 
 static inline size_t sf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Function attributes (dynamic LDS limit) are per device: `seen` is a per-call-site bitmask of the devices
-// that have been set up.  Returns true the first time the current device is seen.
-static inline bool sf_first_use_on_device(unsigned long long* seen) {
+// Function attributes (dynamic LDS limit) are per device, and contexts may be driven from different host threads:
+// a call site owns one sf_dev_once; the set-up of a device runs once, under the site's mutex, and the device is
+// marked only AFTER it succeeded (a second thread never launches before the attribute is in place).
+struct sf_dev_once {
+    std::atomic<unsigned long long> done{0};  // bitmask of the devices that are set up
+    std::mutex mu;
+};
+template <class F>
+static inline int sf_once_per_device(sf_dev_once* once, F&& setup) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return setup();
     const unsigned long long bit = 1ull << dev;
-    if (*seen & bit) return false;
-    *seen |= bit;
-    return true;
+    if (once->done.load(std::memory_order_acquire) & bit) return SF_OK;
+    std::lock_guard<std::mutex> lk(once->mu);
+    if (once->done.load(std::memory_order_relaxed) & bit) return SF_OK;
+    const int rc = setup();
+    if (rc == SF_OK) once->done.fetch_or(bit, std::memory_order_release);
+    return rc;
 }
+#define SF_CHECK(expr)              \
+    do {                            \
+        const int rc_ = (expr);     \
+        if (rc_ != SF_OK) return rc_; \
+    } while (0)
+
+// Tuning / test switches read from the environment exist ONLY in -DSF_TUNING builds (`make TUNING=1` ->
+// libstarfish_amd_tuning.so, loaded by tools/ through SF_LIB_PATH).  The release library has no environment-dependent
+// behaviour: the macros collapse to their defaults and the switch names do not appear in the binary.
+#ifdef SF_TUNING
+#define SF_TUNE_FLAG(name) (getenv(name) != nullptr)
+#define SF_TUNE_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define SF_TUNE_STR(name) (static_cast<const char*>(getenv(name)))
+#else
+#define SF_TUNE_FLAG(name) (false)
+#define SF_TUNE_INT(name, dflt) (dflt)
+#define SF_TUNE_STR(name) (static_cast<const char*>(nullptr))
+#endif
 
 // Streams and events a launch sequence needs besides the caller's stream.  Owned by a context (sf_ctx) or,
 // for the context-free entry points, by the calling thread -- the library keeps no process-global stream state,

@@ -1022,13 +1022,14 @@ static int launch_broaden_t(const sf_broaden_args& a, hipStream_t s) {
     const size_t shm = lds ? sizeof(double2) * (size_t)a.nf : 0;
     dim3 grid(a.rows, a.B);
     if (lds) {
-        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
-        if (sf_first_use_on_device(&attr_seen)) {
+        static sf_dev_once attr_once;  // devices whose function attributes are set
+        SF_CHECK(sf_once_per_device(&attr_once, []() -> int {
             SF_HIP(hipFuncSetAttribute((const void*)k_broaden<true, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             SF_HIP(hipFuncSetAttribute((const void*)k_broaden<false, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            return SF_OK;
+        }));
         hipLaunchKernelGGL((k_broaden<FWD, true>), grid, dim3(256), shm, s, a.in, a.spec, a.rows, a.nf, a.tw,
                            a.dv, a.kind, a.params, a.pstride, a.poff, a.scalar_param, a.out, a.ob, a.orow,
                            a.oelem, (double2*)nullptr, a.info);
@@ -1054,11 +1055,12 @@ static int launch_broaden_half(const sf_broaden_args& a, hipStream_t s) {
     const bool lds = (size_t)(a.nf / 2) <= kLdsFftMax;
     dim3 grid(a.rows, a.B);
     if (lds) {
-        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
-        if (sf_first_use_on_device(&attr_seen)) {
+        static sf_dev_once attr_once;  // devices whose function attributes are set
+        SF_CHECK(sf_once_per_device(&attr_once, []() -> int {
             SF_HIP(hipFuncSetAttribute((const void*)k_broaden_half<true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            return SF_OK;
+        }));
         hipLaunchKernelGGL(k_broaden_half<true>, grid, dim3(256), sizeof(double2) * (size_t)(a.nf / 2), s, a.spec,
                            a.mult, a.rows, a.nf, a.tw, a.kind, a.params, a.pstride, a.poff, a.scalar_param, a.out,
                            a.ob, a.orow, a.oelem, (double2*)nullptr);
@@ -1087,11 +1089,12 @@ int sf_launch_rfft_rows(const double* in, int rows, int nf, const double2* tw, d
                         double2* gscratch, hipStream_t s) {
     const bool lds = (size_t)nf <= kLdsFftMax;
     if (lds) {
-        static unsigned long long attr_seen = 0;  // devices whose function attributes are set
-        if (sf_first_use_on_device(&attr_seen)) {
+        static sf_dev_once attr_once;  // devices whose function attributes are set
+        SF_CHECK(sf_once_per_device(&attr_once, []() -> int {
             SF_HIP(hipFuncSetAttribute((const void*)k_rfft_rows<true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            return SF_OK;
+        }));
         hipLaunchKernelGGL(k_rfft_rows<true>, dim3(rows), dim3(256), sizeof(double2) * (size_t)nf, s, in, nf, tw,
                            spec, (double2*)nullptr);
     } else {

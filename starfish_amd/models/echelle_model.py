@@ -131,11 +131,15 @@ class EchelleModel:
             info[finite] = np.where(bad.any(axis=0), codes[bad.argmax(axis=0), np.arange(codes.shape[1])], 0)
         elif finite.any():
             packed = [m._pack(P[finite], update_caches=False) for m in self.orders]
-            by_dev = {}
+            # one multi-order call per (device, row layout): the C-ABI reads every segment of a call with ONE
+            # ModelDesc (row stride, offsets of the local kernels / Chebyshev terms, has_* flags), so orders whose
+            # descriptors differ -- e.g. a different number of frozen local kernels -- go to separate calls
+            groups = {}
             for idx, (dev, md, rows) in enumerate(packed):
-                by_dev.setdefault(str(dev.dev), []).append(idx)
+                key = (str(dev.dev), dev.m, dev.P, int(np.atleast_2d(rows).shape[1])) + D.model_desc_key(md)
+                groups.setdefault(key, []).append(idx)
             pending = []
-            for idxs in by_dev.values():  # enqueue on every device first, synchronise afterwards
+            for idxs in groups.values():  # enqueue everything first, synchronise afterwards
                 devs = [packed[i][0] for i in idxs]
                 md = packed[idxs[0]][1]
                 pending.append((idxs, D.loglike_multi(devs, md, [packed[i][2] for i in idxs], sync=False)))

@@ -55,3 +55,15 @@ def order_major_units(n_orders, n_walkers):
     rank that owns the slice (cfg 4)."""
     o, w = np.divmod(np.arange(n_orders * n_walkers), n_walkers)
     return np.stack([o, w], axis=1)
+
+
+def order_major_slices(n_orders, n_walkers, lo, hi):
+    """The units [lo, hi) of the order-major list as ``[(order, w_lo, w_hi), ...]``: whole orders in the middle,
+    at most one partial order at either end -- what a rank hands to ``MultiPlan`` (cfg 4: per-order static
+    data is only needed on the ranks that own walkers of that order)."""
+    out = []
+    for o in range(int(n_orders)):
+        w_lo, w_hi = max(lo, o * n_walkers) - o * n_walkers, min(hi, (o + 1) * n_walkers) - o * n_walkers
+        if w_hi > w_lo:
+            out.append((o, int(w_lo), int(w_hi)))
+    return out

@@ -286,3 +286,23 @@ def test_bench_builds_through_the_product_and_keeps_the_oracle_in_the_baseline_l
                 assert name in allowed, f"oracle imported in {name}"
             if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
                 assert name in allowed, f"oracle imported in {name}"
+
+
+def test_release_library_has_no_environment_switches():
+    """The shipped library must not contain a knob that changes its results or launch sequence from the environment
+    (round-2 finding: SF_PANEL_SKIP returned wrong likelihoods by design).  The tuning switches are compiled only
+    under -DSF_TUNING (`make TUNING=1` -> libstarfish_amd_tuning.so); the sources reach the environment through
+    the SF_TUNE_* macros alone."""
+    from starfish_amd import _lib
+
+    blob = open(os.path.join(ROOT, "starfish_amd", "libstarfish_amd.so"), "rb").read()
+    for name in (b"SF_PANEL_SKIP", b"SF_CHOL_UNFUSED", b"SF_CHOL_SPLIT", b"SF_NO_LOOKAHEAD", b"SF_MULTI_FIRST",
+                 b"SF_BAND_NO_TWIST", b"SF_BAND_TILES_POISON", b"SF_DIAG_SCRATCH"):
+        assert name not in blob, name
+    assert os.path.basename(_lib.LIB_PATH) == "libstarfish_amd.so"
+    csrc = os.path.join(ROOT, "starfish_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".h")):
+            for ln in open(os.path.join(csrc, f)):
+                if "getenv" in ln:
+                    assert f == "sf_common.h" and "#define SF_TUNE_" in ln, (f, ln)
