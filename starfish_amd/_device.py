@@ -94,7 +94,10 @@ def factor_v11(v11, w_hat):
     the host, once per hyper-parameter set -- every order context of the emulator receives the same arrays."""
     from scipy.linalg import cho_solve, cholesky, solve_triangular
 
-    L = cholesky(np.asarray(v11, dtype=np.float64), lower=True)
+    try:
+        L = cholesky(np.asarray(v11, dtype=np.float64), lower=True)
+    except np.linalg.LinAlgError as e:  # the library's documented status for this case (SF_INFO_EMULATOR_NOT_PD)
+        raise np.linalg.LinAlgError(INFO_MESSAGES[-3]) from e
     linv = np.tril(solve_triangular(L, np.eye(L.shape[0]), lower=True))
     alpha = cho_solve((L, True), np.asarray(w_hat, dtype=np.float64))
     return np.ascontiguousarray(linv), np.ascontiguousarray(alpha)
@@ -313,12 +316,19 @@ class DeviceOrder:
         per = self.workspace_bytes(md, 1)
         return max(1, budget // max(per, 1))
 
-    def _work(self, md, B):
-        need = self.workspace_bytes(md, B)
+    def _reserve(self, need):
+        """The order's workspace, grown to ``need`` bytes.  The buffer is handed to kernels on whatever stream is
+        current (EchelleModel rotates orders over side streams), so that stream is recorded on it: the caching
+        allocator then does not recycle a dropped buffer before the work queued on it has finished."""
+        torch = _torch()
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = workspace(need, self.dev)
+        self._ws.record_stream(torch.cuda.current_stream(self.dev))
         return self._ws
+
+    def _work(self, md, B):
+        return self._reserve(self.workspace_bytes(md, B))
 
     def release_workspace(self):
         self._ws = None
@@ -341,11 +351,7 @@ class DeviceOrder:
         return self.lib.sf_banded_workspace_bytes(self.ctx, C.byref(md), int(B), int(halfwidth))
 
     def _work_banded(self, md, B, halfwidth):
-        need = self.banded_workspace_bytes(md, B, halfwidth)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = workspace(need, self.dev)
-        return self._ws
+        return self._reserve(self.banded_workspace_bytes(md, B, halfwidth))
 
     def loglike_banded_device(self, md, P_dev, halfwidth, out_lnl, info=None, logdet=None, sqmah=None,
                               resid=None, log_scale=None):
@@ -420,9 +426,13 @@ class DeviceOrder:
         # two groups: the cost of the wide-band factorisation grows with the half-width, so the walkers that fit the
         # LDS window are not dragged along with the wide ones
         wwin = self.banded_window_halfwidth()
-        for idx in (np.nonzero(fits & (hw <= wwin))[0], np.nonzero(fits & (hw > wwin))[0]):
-            if not idx.size:
-                continue
+        parts = [idx for idx in (np.nonzero(fits & (hw <= wwin))[0], np.nonzero(fits & (hw > wwin))[0]) if idx.size]
+        # ONE allocation for both groups, made before anything is enqueued: the second group must not drop the
+        # buffer the first group's kernels are still queued on
+        if parts:
+            self._reserve(max(self.banded_workspace_bytes(md, min(idx.size, max_chunk or idx.size), int(hw[idx].max()))
+                              for idx in parts))
+        for idx in parts:
             W = int(hw[idx].max())
             with torch.cuda.device(self.dev):
                 P = to_dev(rows[idx], self.dev)

@@ -1307,6 +1307,31 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             const double* Ab = A2 + cur * GT * GK;
             const double* Bb = B2 + cur * GT * GK;
             if (!wave_live) return;
+#ifdef SF_EXP_FRAGPF
+            double2 a[2][TM], bb[2][TN];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * (16 * TM) + i * 16 + l15;
+                    a[h][i] = *(const double2*)(Ab + row * GK + 2 * ((2 * lq + h) ^ sf_swz(row)));
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const int row = wn * (16 * TN) + i * 16 + l15;
+                    bb[h][i] = *(const double2*)(Bb + row * GK + 2 * ((2 * lq + h) ^ sf_swz(row)));
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h][mi].x, bb[h][ni].x, acc[mi][ni], 0, 0, 1);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h][mi].y, bb[h][ni].y, acc[mi][ni], 0, 0, 1);
+                    }
+#else
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 double2 a[TM], bb[TN];
@@ -1320,6 +1345,9 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
                     const int row = wn * (16 * TN) + i * 16 + l15;
                     bb[i] = *(const double2*)(Bb + row * GK + 2 * ((2 * lq + h) ^ sf_swz(row)));
                 }
+#ifdef SF_EXP_SETPRIO
+                __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -1327,13 +1355,19 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi].x, bb[ni].x, acc[mi][ni], 0, 0, 1);  // neg:[1,0,0]
                         acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi].y, bb[ni].y, acc[mi][ni], 0, 0, 1);
                     }
+#ifdef SF_EXP_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
+#endif
         };
         for (int kt = 0; kt + 1 < nk; ++kt) {
             gload(kbeg + kt + 1, (kt & 1) ^ 1);
             compute(kt & 1);
             gwait();
+#ifndef SF_EXP_NOBARRIER
             __syncthreads();
+#endif
         }
         if (nk > 0) compute((nk - 1) & 1);
         __syncthreads();  // the epilogue re-uses the LDS with its own layouts

@@ -85,9 +85,10 @@ class Emulator:
     def v11_factor(self):
         """(Linv, alpha) of the current v11, computed once per hyper-parameter set and handed to every order
         context built on this emulator."""
-        if self._factor is None:
-            self._factor = D.factor_v11(self.v11, self.w_hat)
-        return self._factor
+        if self._factor is None or self._factor[0] is not self.v11 or self._factor[1] is not self.w_hat:
+            # keyed on the arrays themselves: any reassignment of v11 / w_hat invalidates the factor
+            self._factor = (self.v11, self.w_hat, D.factor_v11(self.v11, self.w_hat))
+        return self._factor[2]
 
     @property
     def lambda_xi(self):

@@ -110,6 +110,11 @@ class SpectrumModel:
         key = tuple(zlib.crc32(np.ascontiguousarray(a)) for a in (d.wave, d.flux, d.sigma))
         stale = self._dev is None or self._dev_v11 is not emu.v11 or key != self._dev_data
         if stale:
+            if self._dev_data is not None and key[0] != self._dev_data[0]:
+                # a new wavelength grid: what the constructor derived from it (spectrum_model.py:150-156) follows
+                dv = calculate_dv(d.wave)
+                self.min_dv_wave = create_log_lam_grid(dv, emu.wl.min(), emu.wl.max())["wl"]
+                self._bulk_fluxes = None
             self._dev_data = key
             self._dev = D.DeviceOrder(
                 self.data.wave, self.data.flux, self.data.sigma, self.min_dv_wave, self.bulk_fluxes,

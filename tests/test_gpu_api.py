@@ -260,3 +260,24 @@ def test_realistic_emulator_size_vs_reference():
     plain = D.DeviceOrder(*dev._keep[:10])
     md, rows = m._pack(g["batch_P"], update_caches=False)[1:]
     np.testing.assert_allclose(plain.loglike(md, rows)["lnl"], dev.loglike(md, rows)["lnl"], rtol=1e-12)
+
+
+def test_emulator_training_likelihood_worked_example_size_vs_reference():
+    """Emulator.log_likelihood() at the size of the reference's worked example (m = 4, M = 330: one
+    1320 x 1320 Cholesky per objective call of Emulator.train, emulator.py:484-524,602-619) against the reference's
+    values for two hyper-parameter vectors (tests/golden/emulator_train_big.npz)."""
+    g = load_golden("emulator_train_big.npz")
+    o = synth.make_order(N=256, m=4, seed=13, grid_axes=synth.BIG_GRID_AXES)
+    emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"],
+                   o["w_hat"], o["flux_mean"], o["flux_std"], o["factors"])
+    assert emu.v11.shape == (1320, 1320)
+    assert list(g["labels"]) == list(emu.get_param_dict().keys())
+    np.testing.assert_allclose(emu.get_param_vector(), g["P0"], rtol=1e-14)
+    want = g["lnl0"][0]
+    assert abs(emu.log_likelihood() - want) <= 1e-9 * abs(want)
+    emu.set_param_vector(g["P1"])
+    np.testing.assert_allclose(np.trace(emu.v11), g["v11_trace1"][0], rtol=1e-13)
+    want = g["lnl1"][0]
+    got = emu.log_likelihood()
+    assert abs(got - want) <= 1e-9 * abs(want), (got, want)
+    assert got == emu.log_likelihood()  # deterministic

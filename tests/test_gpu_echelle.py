@@ -130,3 +130,44 @@ def test_two_contexts_on_two_threads_match_serial():
         np.testing.assert_array_equal(r, want1[0])
     for r in got[2]:
         np.testing.assert_array_equal(r, want2[0])
+
+
+def test_orders_with_different_descriptors_vs_oracle():
+    """orders whose parameter-row layouts differ -- another number of frozen local kernels, no
+    local kernel at all -- expose the same thawed labels but must not share one sf_loglike_multi_batch call (the
+    C-ABI reads all segments of a call with ONE ModelDesc).  Per-order values against the oracle."""
+    orders = [synth.make_order(N=n, m=4, seed=80 + i, wave0=5000.0 * 1.02**i) for i, n in enumerate((256, 320, 192, 256))]
+    kernels = []
+    models = []
+    for i, o in enumerate(orders):
+        c = dict(synth.centre_params(o))
+        w = o["wave"]
+        if i == 1:  # two local kernels
+            c["local_cov"] = list(c["local_cov"]) + [dict(mu=float(w[len(w) // 2]), log_amp=-8.5, log_sigma=float(np.log(10.0)))]
+        if i == 2:  # none
+            del c["local_cov"]
+        kernels.append([(k["mu"], k["log_amp"], k["log_sigma"]) for k in c.get("local_cov", [])])
+        models.append(synth.build_model(o, params=c, freeze=("local_cov",) if "local_cov" in c else ()))
+    from starfish_amd.models import EchelleModel
+
+    em = EchelleModel.from_orders(models)
+    assert em.labels == synth.SHARED_LABELS
+    strides = {m._pack(None)[2].shape[1] for m in models}
+    assert len(strides) == 3  # really different row layouts
+    P = synth.shared_ball(orders[0], B=5, seed=4)
+    total, info, per_order = em.log_likelihood_batch(P, return_info=True, return_orders=True)
+    assert (info == 0).all()
+    for i, o in enumerate(orders):
+        oo = oracle_order(o)
+        for b, p in enumerate(P):
+            q = synth.shared_to_oracle_params(o, p)
+            q["local_cov"] = kernels[i]
+            if not kernels[i]:
+                del q["local_cov"]
+            want = O.log_likelihood(oo, q)
+            assert close(per_order[i, b], want), (i, b, per_order[i, b], want)
+    assert close(total, per_order.sum(axis=0), rtol=1e-14)
+    # a MultiPlan asked to mix the layouts refuses
+    packed = [m._pack(P, update_caches=False) for m in models]
+    with pytest.raises(ValueError):
+        D.MultiPlan([p[0] for p in packed], packed[0][1], [p[2] for p in packed])

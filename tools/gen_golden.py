@@ -371,6 +371,60 @@ def gen_cfg3(n_orders=25, N=3000, nwalk=3):
     print("model_cfg3.npz", lnl.sum(axis=0))
 
 
+# ------------------------------------- full BASELINE batches: the LAST walker of each config's bench batch
+def gen_fullbatch():
+    """The parity tests at the BASELINE batch sizes (cfg 2: 128 walkers, cfg 3: 25 orders x 64, cfg 5: 32) compare the
+    first walkers with model_cfg2 / model_cfg3 and the LAST walker of each batch (plus walker 0 of cfg 5's ball)
+    with these values of the reference."""
+    import time
+
+    out = {}
+    o = synth.make_order(N=4096)
+    model = ref_model(o)
+    P = synth.walker_ball(o, B=128)
+    model.set_param_vector(P[127])
+    out["cfg2_P127"], out["cfg2_lnl127"] = P[127], np.array([model.log_likelihood()])
+    print("  cfg2 walker 127", out["cfg2_lnl127"])
+    orders = synth.make_echelle(25, 3000)
+    Ps = synth.shared_ball(orders[0], B=64)
+    lnl = np.zeros(25)
+    for k, order in enumerate(orders):
+        model = ref_model(order)
+        model.freeze("local_cov")
+        model.set_param_vector(Ps[63])
+        lnl[k] = model.log_likelihood()
+    out["cfg3_P63"], out["cfg3_lnl63"] = Ps[63], lnl
+    print("  cfg3 walker 63", lnl.sum())
+    o = synth.make_order(N=16384)
+    model = ref_model(o)
+    P = synth.walker_ball(o, B=32)
+    vals = []
+    for b in (0, 31):
+        t0 = time.time()
+        model.set_param_vector(P[b])
+        vals.append(model.log_likelihood())
+        print("  cfg5 walker", b, vals[-1], f"{time.time() - t0:.0f} s")
+    out["cfg5_P"], out["cfg5_lnl"] = P[[0, 31]], np.array(vals)
+    np.savez_compressed(os.path.join(OUT, "model_fullbatch.npz"), **out)
+    print("model_fullbatch.npz", len(out))
+
+
+def gen_emulator_train_big():
+    """Emulator.log_likelihood() (emulator.py:602-619) at the worked-example size m = 4, M = 330 (a 1320 x 1320
+    cho_factor per objective call, examples/setup.ipynb:47,185,215) for two hyper-parameter vectors."""
+    o = synth.make_order(N=256, m=4, seed=13, grid_axes=synth.BIG_GRID_AXES)
+    emu, _ = ref_objects(o)
+    P0 = emu.get_param_vector()
+    out = {"P0": P0, "labels": np.array(list(emu.get_param_dict().keys())), "lnl0": np.array([emu.log_likelihood()])}
+    rng = np.random.default_rng(17)
+    P1 = P0 + rng.uniform(-0.3, 0.3, len(P0))
+    emu.set_param_vector(P1)
+    out["P1"], out["lnl1"] = P1, np.array([emu.log_likelihood()])
+    out["v11_trace1"] = np.array([np.trace(emu.v11)])
+    np.savez_compressed(os.path.join(OUT, "emulator_train_big.npz"), **out)
+    print("emulator_train_big.npz", out["lnl0"], out["lnl1"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     big = "--big" in sys.argv
@@ -395,6 +449,10 @@ if __name__ == "__main__":
         gen_cfg3()
     if "emulator_big" in only:
         gen_emulator_big()
+    if "emulator_train_big" in only:
+        gen_emulator_train_big()
+    if "fullbatch" in only:
+        gen_fullbatch()
     if big:
         gen_model_large([4096], {4096: 8}, "cfg2")
         gen_model_large([16384], {}, "cfg5")
