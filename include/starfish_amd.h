@@ -306,10 +306,13 @@ int sf_band_logdet_gram_batch(const double* d_band, int n, int halfwidth, int ld
 int sf_profile_enable(int on);
 int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches, long* calls);
 
-/* Tuning / test aid (process-global): the batched Cholesky has two launch sequences -- the fused panel kernel
- * (128-column panels; faster once the batch fills the chip) and the unfused one (256-column panels, separate
- * panel-solve and diagonal-update launches; fewer sequential steps, faster for batches below ~28 matrices).
- * mode -1 = choose by batch size (default), 0 = always fused, 1 = always unfused.  Same results to rounding. */
+/* Tuning / test aid (process-global): the batched Cholesky has three launch sequences -- the fused panel kernel
+ * (128-column panels, two workgroups per CU; the default once the batch fills the chip), the unfused one (256-column
+ * panels, separate panel-solve and diagonal-update launches; fewer sequential steps, faster for batches below ~28
+ * matrices) and the wide one (pairs of panels, one 16-wave workgroup per CU keeps a 128 x 256 tile: a third less HBM
+ * traffic; taken for full batches, 96-512 matrices of 2048-8192 rows).
+ * mode -1 = choose by batch and matrix size (default), 0 = always fused, 1 = always unfused, 2 = always wide.
+ * Same results to rounding. */
 int sf_debug_cholesky_sequence(int mode);
 
 /* Tuning aid: one wave spins for `wall_ticks_100mhz` ticks of the 100 MHz wall clock on `stream` and

@@ -113,6 +113,7 @@ int sf_exec_prepare(sf_exec* ex) {
         SF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         SF_HIP(hipStreamCreateWithPriority(&ex->side, hipStreamNonBlocking, prio_hi));
         SF_HIP(hipStreamCreateWithFlags(&ex->aux, hipStreamNonBlocking));
+        SF_HIP(hipStreamCreateWithPriority(&ex->xa, hipStreamNonBlocking, prio_hi));
         for (int g = 0; g < SF_EXEC_GROUPS - 1; ++g) SF_HIP(hipStreamCreateWithFlags(&ex->grp[g], hipStreamNonBlocking));
         SF_HIP(hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming));
         SF_HIP(hipEventCreateWithFlags(&ex->join, hipEventDisableTiming));
@@ -150,12 +151,13 @@ void sf_exec_release(sf_exec* ex) {
     if (ex->join) (void)hipEventDestroy(ex->join);
     if (ex->side) (void)hipStreamDestroy(ex->side);
     if (ex->aux) (void)hipStreamDestroy(ex->aux);
+    if (ex->xa) (void)hipStreamDestroy(ex->xa);
     for (int g = 0; g < SF_EXEC_GROUPS - 1; ++g) {
         if (ex->grp[g]) (void)hipStreamDestroy(ex->grp[g]);
         ex->grp[g] = nullptr;
     }
     ex->fork = ex->join = nullptr;
-    ex->side = ex->aux = nullptr;
+    ex->side = ex->aux = ex->xa = nullptr;
     ex->device = -1;
 }
 // context-free entry points (sf_potrf_batch, ...): one sf_exec per calling thread and device

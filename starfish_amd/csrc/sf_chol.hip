@@ -17,6 +17,7 @@
 //   k_trsv_logdet: the stand-alone forward substitution of sf_logdet_sqmah_batch.
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "sf_common.h"
@@ -1191,7 +1192,11 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         for (int q = 0; q < 2; ++q) {
             const int row = 16 * w + 8 * q + grow;
             const int c = gpos ^ sf_swz(row);
+#ifdef SF_EXP_AL2  // timing only: every slab streams the rows of the panel's first slab (L2-resident A operand)
+            Ag[q] = Cb + (int64_t)(k0 + (k0 + 2 * GT <= g.n ? GT : 0) + min(row, rows_here - 1)) * g.lda + 2 * c;
+#else
             Ag[q] = Cb + (int64_t)(row0 + min(row, rows_here - 1)) * g.lda + 2 * c;
+#endif
             Bg[q] = Cb + (int64_t)(k0 + min(row, pw - 1)) * g.lda + 2 * c;
         }
         typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -1335,6 +1340,12 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 double2 a[TM], bb[TN];
+#ifdef SF_EXP_NOLDSREAD
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" : "=v"(a[i].x), "=v"(a[i].y));
+#pragma unroll
+                for (int i = 0; i < TN; ++i) asm volatile("" : "=v"(bb[i].x), "=v"(bb[i].y));
+#else
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = wm * (16 * TM) + i * 16 + l15;
@@ -1345,6 +1356,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
                     const int row = wn * (16 * TN) + i * 16 + l15;
                     bb[i] = *(const double2*)(Bb + row * GK + 2 * ((2 * lq + h) ^ sf_swz(row)));
                 }
+#endif
 #ifdef SF_EXP_SETPRIO
                 __builtin_amdgcn_s_setprio(3);
 #endif
@@ -1362,7 +1374,9 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
 #endif
         };
         for (int kt = 0; kt + 1 < nk; ++kt) {
+#ifndef SF_EXP_NOGLOAD
             gload(kbeg + kt + 1, (kt & 1) ^ 1);
+#endif
             compute(kt & 1);
             gwait();
 #ifndef SF_EXP_NOBARRIER
@@ -1567,6 +1581,439 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         __syncthreads();
         if (tid < rows_here) g.rhs[(int64_t)b * g.ldr + row0 + tid] -= red[0][tid] + red[1][tid];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// WIDE fused panel step: a PAIR of 128-column panels [k0, k0 + 256) per launch.  ONE workgroup of 16 waves (1024
+// threads, one per CU: 148 KB of LDS, 4 waves per SIMD) owns a 128-row slab and keeps the 128 x 256 tile in its
+// accumulators (wave = 32 rows x 64 columns: two 16-column blocks of each panel), so the slab's L[slab, :k0] -- the
+// A operand, the stream that comes from HBM -- is read once per 256 columns instead of once per 128: half the HBM
+// traffic of the long-K update, three quarters of the L2 -> LDS traffic, half the tile read-modify-writes and half
+// the launches of k_chol_panel.  The factorisation is POWER-bound at these batch sizes (profiles/r03_*: the same
+// instruction stream with the operands kept in L2 runs 5 % faster at a 5 % higher clock), so traffic is time.
+//   1  T  = C[slab, pair] - L[slab, :k0] L[pair rows, :k0]^T      K slabs of 16 through a THREE-stage LDS ring filled
+//         by direct global -> LDS loads; the fragments of the next half slab are read before the barrier (the data of
+//         slab k+1 is complete one barrier earlier), so no wave waits for LDS after a barrier
+//   2a L1 = T1 W_k            (W_k = L_kk^-T, explicit inverse from k_diag_lds; descending 32-column chunks as in
+//                              k_chol_panel: a wave dumps its T blocks when its registers become the L accumulators)
+//   2b T2 -= L1 L21^T         (L21 = L[panel k+1 rows, panel k columns], left in place by the chain's narrow step)
+//   2c L2 = T2 W_k+1
+//   3  L -> C in place, rhs[slab] -= L1 z_k + L2 z_k+1
+//   4  S  = C[slab, slab] - L L^T (K = 256): waves 0-7 take the columns of panel k, waves 8-15 those of panel k+1 in the
+//         36-blocks-on-8-waves layout of k_chol_panel; the two halves are added through LDS in fixed order
+// Same arithmetic as two consecutive k_chol_panel steps; the summation order of 2b differs (natural k order instead
+// of the K-permuted fragments), so results agree to rounding, not bit for bit.
+#define WST (3 * GT * GK)  // doubles per LDS stage: A 128 x 16, B 256 x 16
+#define SF_PANELW_LDS ((3 * WST + 4 * GT) * sizeof(double))
+struct sf_panelw_args {
+    double* C;
+    int64_t sC;
+    int lda, n;
+    int k0;            // pair columns [k0, k0 + 256), both panels full
+    int row0, nslab;   // nslab slabs of 128 rows, the first at row0; the last may be shorter
+    int slab_step;     // distance between the slabs of this launch, in slabs (the two slab groups are interleaved)
+    const double* Wt0; // [batch] x sW: (L_kk^-1)[c][k], row stride SF_LDT
+    const double* Wt1; // ... of panel k + 1
+    int64_t sW;
+    double* rhs;
+    int ldr;
+    double* Sout;      // the first slab's updated diagonal tile goes here (next diagonal tile) when non-NULL
+    int64_t sS;
+    int ldS;
+    const double* genY;
+    const unsigned char* tilemap;
+    int64_t sY;
+    int ldy, mpad, nt128;
+};
+
+template <bool RHS>
+__global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
+    constexpr int TM = 2, TN = 4;
+    extern __shared__ __attribute__((aligned(16))) double smw[];
+    double* red = smw + 3 * WST;  // [4][GT]
+
+    const int id = sf_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = id / g.nslab;
+    const int sl = id - b * g.nslab;
+    const int row0 = g.row0 + sl * g.slab_step * GT;
+    const int rows_here = min(GT, g.n - row0);
+    const int k0 = g.k0;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the four waves of a SIMD (w, w + 4, w + 8, w + 12) share a row group and take the four column groups: the
+    // triangular phases give the column groups different amounts of work, every SIMD gets the same total
+    const int wm = w & 3, wn = w >> 2;
+    const int l15 = lane & 15, lq = lane >> 4;
+    double* Cb = g.C + (int64_t)b * g.sC;
+    // block ni of this wave: columns bc(ni) .. + 16 of the pair (ni 0, 1: panel k; ni 2, 3: panel k + 1)
+#define WBC(ni) ((((ni) >> 1) * GT) + wn * 32 + (((ni)&1) * 16))
+    const bool wave_live = wm * 32 < rows_here;
+
+    sf_d4 acc[TM][TN];
+    // ---------------------------------------------------------------- 1: long-K update
+    {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smw;
+        const int grow = lane >> 3, gpos = lane & 7;
+        // 384 rows of 8 granules per stage = 48 groups of 8 rows, three per wave; groups 0-15 are A rows, 16-47 B rows
+        const double* src[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int G = 3 * w + j;
+            const bool isA = G < 16;
+            const int r = (isA ? G : G - 16) * 8 + grow;
+            const int c = gpos ^ sf_swz(r);
+            src[j] = Cb + (int64_t)(isA ? row0 + min(r, rows_here - 1) : k0 + r) * g.lda + 2 * c;
+        }
+        auto glds16 = [&](const double* p, unsigned lds_dst) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(p), "s"(lds_dst)
+                         : "memory");
+        };
+        auto gload = [&](int kt, int stage) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) glds16(src[j] + kt * GK, lds0 + (unsigned)(stage * WST * 8 + (3 * w + j) * 1024));
+        };
+        auto gwait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        const int nk = k0 / GK;
+        if (nk > 0) gload(0, 0);
+        if (nk > 1) gload(1, 1);
+
+        // start of the tile: generated as Y^T Y (never materialised) or read from C, per 128-column half
+        bool gen_half[2] = {false, false};
+        if (g.tilemap) {
+            const unsigned char* tm = g.tilemap + (int64_t)b * g.nt128 * g.nt128 + (row0 / GT) * g.nt128 + k0 / GT;
+            gen_half[0] = !tm[0];
+            gen_half[1] = !tm[1];
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (gen_half[hf]) {
+                const double* Yb = g.genY + (int64_t)b * g.sY;
+                const int gr = row0 + wm * 32 + l15;
+                const int gc = k0 + hf * GT + wn * 32 + l15;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) acc[mi][2 * hf + nn] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk < g.mpad; kk += 4) {
+                    const double* yk = Yb + (int64_t)(kk + lq) * g.ldy;
+                    double ya[TM], yb[2];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) ya[i] = yk[min(gr + i * 16, g.ldy - 1)];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) yb[i] = yk[min(gc + i * 16, g.ldy - 1)];
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int nn = 0; nn < 2; ++nn)
+                            acc[mi][2 * hf + nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[mi], yb[nn], acc[mi][2 * hf + nn], 0, 0, 0);
+                }
+            } else {
+                const double* Cin = Cb + (int64_t)row0 * g.lda + k0;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) {
+                        const int col = WBC(2 * hf + nn) + l15;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = wm * 32 + mi * 16 + lq + 4 * r;
+                            acc[mi][2 * hf + nn][r] = row < rows_here ? Cin[(int64_t)row * g.lda + col] : 0.0;
+                        }
+                    }
+            }
+        }
+        gwait();
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(acc[mi][ni][r]));
+
+        // fragment reads (layout and swizzle of k_chol_panel; sf_swz of a fragment row depends on l15 only)
+        const int sw = sf_swz(l15);
+        const int e0 = 2 * ((2 * lq) ^ sw), e1 = 2 * ((2 * lq + 1) ^ sw);
+        const int arow = (wm * 32 + l15) * GK, brow = (GT + wn * 32 + l15) * GK;
+        auto frag = [&](int stage, int h, double2(&a)[TM], double2(&bb)[TN]) {
+            const double* S = smw + stage * WST + (h ? e1 : e0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const double2*)(S + arow + i * 16 * GK);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) bb[i] = *(const double2*)(S + brow + ((i >> 1) * GT + (i & 1) * 16) * GK);
+        };
+        auto mfma16 = [&](const double2(&a)[TM], const double2(&bb)[TN]) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi].x, bb[ni].x, acc[mi][ni], 0, 0, 1);  // neg:[1,0,0]
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi].y, bb[ni].y, acc[mi][ni], 0, 0, 1);
+                }
+        };
+        double2 a0[TM], b0[TN], a1[TM], b1[TN];
+        int s0 = 0, s1 = 1, s2 = 2;  // stages of slab kt, kt + 1, kt + 2
+        if (nk > 0 && wave_live) frag(0, 0, a0, b0);
+        for (int kt = 0; kt < nk; ++kt) {
+#ifndef SF_EXPW_NOGLOAD
+            if (kt + 2 < nk) gload(kt + 2, s2);
+#endif
+            if (wave_live) {
+                frag(s0, 1, a1, b1);
+                mfma16(a0, b0);
+                if (kt + 1 < nk) frag(s1, 0, a0, b0);  // complete since the previous barrier
+                mfma16(a1, b1);
+            }
+            gwait();
+#ifndef SF_EXPW_NOBARRIER
+            __syncthreads();
+#endif
+            const int t = s0;
+            s0 = s1;
+            s1 = s2;
+            s2 = t;
+        }
+    }
+
+    // ---------------------------------------------------------------- 2: triangular solves through LDS
+    double* Ach = smw;                          // [128][CLD] chunk of the A operand (accumulator -> operand layout)
+    double* Bs = smw + GT * CLD;                // [2][128][GLD] 16-column blocks of W  /  [128][CLD] chunk of L21
+    const int lr = tid >> 3, lc = (tid & 7) * 2;  // staging: 128 rows x 8 threads
+    // L = T W on the blocks NB, NB + 1 of every wave (NB = 0: panel k, NB = 2: panel k + 1), K blocks in descending order
+    auto solve = [&](const double* Wt, auto nbtag) {
+        constexpr int NB = decltype(nbtag)::value;
+        const double* Wp = Wt + (int64_t)b * g.sW + (int64_t)lr * SF_LDT + lc;
+        double2 rw = *(const double2*)(Wp + 7 * 16);
+        int buf = 0;
+#pragma unroll
+        for (int sbi = 0; sbi < 8; ++sbi) {
+            const int sb = 7 - sbi;
+            if (sb & 1) {  // first block of chunk sb / 2: its owner waves hand their T blocks over
+                __syncthreads();
+                if (wn == (sb >> 1)) {
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                Ach[(wm * 32 + mi * 16 + lq + 4 * r) * CLD + nn * 16 + l15] = acc[mi][NB + nn][r];
+                            acc[mi][NB + nn] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+                        }
+                }
+            }
+            {
+                double* pb = Bs + buf * (GT * GLD) + lr * GLD + lc;
+                pb[0] = rw.x;
+                pb[1] = rw.y;
+            }
+            __syncthreads();
+            if (sb > 0) rw = *(const double2*)(Wp + (sb - 1) * 16);
+            // W[k][c] = 0 for k > c: the wave's columns (blocks 2 wn, 2 wn + 1 of the panel) need K blocks <= 2 wn + 1
+            if (sb <= 2 * wn + 1 && wave_live) {
+                const double* Ab = Ach + (wm * 32 + l15) * CLD + (sb & 1) * 16 + lq;
+                const double* Bb = Bs + buf * (GT * GLD) + (wn * 32 + l15) * GLD + lq;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    double a[TM], bb[2];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = Ab[i * 16 * CLD + ks * 4];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bb[i] = Bb[i * 16 * GLD + ks * 4];
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int nn = 0; nn < 2; ++nn)
+                            acc[mi][NB + nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[nn], acc[mi][NB + nn], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+    };
+    __syncthreads();  // (the main loop's last reads of the ring are done)
+    solve(g.Wt0, std::integral_constant<int, 0>());
+
+    // 2b: T2 -= L1 L21^T, 32 columns of L1 at a time (chunk q = the blocks of the waves wn == q)
+    {
+        const double* L21 = Cb + (int64_t)(k0 + GT + lr) * g.lda + k0 + (tid & 7) * 4;
+        double* Bc = Bs;  // [128][CLD]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 l0 = *(const double2*)(L21 + q * 32);
+            const double2 l1 = *(const double2*)(L21 + q * 32 + 2);
+            __syncthreads();  // previous chunk consumed
+            if (wn == q) {
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            Ach[(wm * 32 + mi * 16 + lq + 4 * r) * CLD + nn * 16 + l15] = acc[mi][nn][r];
+            }
+            {
+                double* pb = Bc + lr * CLD + (tid & 7) * 4;
+                pb[0] = l0.x;
+                pb[1] = l0.y;
+                pb[2] = l1.x;
+                pb[3] = l1.y;
+            }
+            __syncthreads();
+            if (wave_live) {
+                const double* Ab = Ach + (wm * 32 + l15) * CLD + lq;
+                const double* Bb = Bc + (wn * 32 + l15) * CLD + lq;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    double a[TM], bb[2];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = Ab[i * 16 * CLD + ks * 4];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bb[i] = Bb[i * 16 * CLD + ks * 4];
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int nn = 0; nn < 2; ++nn)
+                            acc[mi][2 + nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[nn], acc[mi][2 + nn], 0, 0, 1);  // neg
+                }
+            }
+        }
+    }
+    solve(g.Wt1, std::integral_constant<int, 2>());
+
+    // ---------------------------------------------------------------- 3: L in place, rhs -= L z
+    {
+        double* Lout = Cb + (int64_t)row0 * g.lda + k0;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = WBC(ni) + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * 32 + mi * 16 + lq + 4 * r;
+                    if (row < rows_here) Lout[(int64_t)row * g.lda + col] = acc[mi][ni][r];
+                }
+            }
+        if (RHS && g.rhs) {
+            const double* z = g.rhs + (int64_t)b * g.ldr + k0;
+            double zc[TN];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) zc[ni] = z[WBC(ni) + l15];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) v = __builtin_fma(acc[mi][ni][r], zc[ni], v);
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    if (l15 == 0) red[wn * GT + wm * 32 + mi * 16 + lq + 4 * r] = v;
+                }
+        }
+    }
+
+    // ---------------------------------------------------------------- 4: S = C[slab, slab] - L L^T, K = 256
+    {
+        const int hg = w >> 3, w8 = w & 7;  // K half (panel) and position in the 8-wave block layout
+        const int p = w8 >> 1, h = w8 & 1;
+        int bi[5], bj[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (h == 0) {
+                bi[q] = 7 - p;
+                bj[q] = q;
+            } else {
+                const int n_hi = 3 - p;  // blocks 5 .. 7-p of row 7-p, then blocks 0 .. p of row p
+                const int qq = q < 4 ? q : 0;
+                bi[q] = qq < n_hi ? 7 - p : p;
+                bj[q] = qq < n_hi ? 5 + qq : qq - n_hi;
+            }
+        }
+        const int nstore = h == 0 ? 5 : 4;
+        const int t5 = tid & 511;
+        const int lr2 = t5 >> 3, lc2 = (t5 & 7) * 2;
+        double* As2 = smw + hg * (2 * GT * GLD);  // [2][128][GLD] per K half
+        const double* Lp[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) Lp[q] = Cb + (int64_t)(row0 + min(lr2 + 64 * q, rows_here - 1)) * g.lda + k0 + hg * GT + lc2;
+        double2 rl[2];
+        auto gload2 = [&](int kt) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) rl[q] = *(const double2*)(Lp[q] + kt * GK);
+        };
+        auto lstore2 = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                double* pa = As2 + buf * (GT * GLD) + (lr2 + 64 * q) * GLD + lc2;
+                pa[0] = rl[q].x;
+                pa[1] = rl[q].y;
+            }
+        };
+        __syncthreads();  // the L slab is visible to every wave of the workgroup; the LDS buffers are free
+        gload2(0);
+        const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
+        sf_d4 acc2[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
+                acc2[q][r] = (hg == 0 && q < nstore && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
+            }
+        lstore2(0);
+        __syncthreads();
+        constexpr int nk2 = GT / GK;
+        for (int kt = 0; kt < nk2; ++kt) {
+            if (kt + 1 < nk2) gload2(kt + 1);
+            const double* S = As2 + (kt & 1) * (GT * GLD) + l15 * GLD + lq;
+#pragma unroll
+            for (int ks = 0; ks < GK / 4; ++ks) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[bi[q] * 16 * GLD + ks * 4], S[bj[q] * 16 * GLD + ks * 4],
+                                                                   acc2[q], 0, 0, 1);  // neg:[1,0,0]
+            }
+            if (kt + 1 < nk2) lstore2((kt & 1) ^ 1);
+            __syncthreads();
+        }
+        // the panel k + 1 half goes through LDS and is added by the panel k half (fixed order: deterministic)
+        double* Rd = smw + (w8 * 5) * 256 + lane * 4;
+        if (hg == 1) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) *(sf_d4*)(Rd + q * 256) = acc2[q];
+        }
+        __syncthreads();
+        if (hg == 0) {
+            const bool parked = g.Sout && sl == 0;
+            double* So = parked ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
+            const int ldo = parked ? g.ldS : g.lda;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                if (q >= nstore) continue;
+                const sf_d4 o = *(const sf_d4*)(Rd + q * 256);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
+                    if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[q][r] + o[r];
+                }
+            }
+        }
+    }
+    if (RHS && g.rhs) {
+        // (red was written before the barriers of step 4)
+        if (tid < rows_here)
+            g.rhs[(int64_t)b * g.ldr + row0 + tid] -= (red[tid] + red[GT + tid]) + (red[2 * GT + tid] + red[3 * GT + tid]);
+    }
+#undef WBC
 }
 
 // The per-matrix scratch strides are skewed by a few hundred bytes: with strides that are multiples of
@@ -1807,8 +2254,8 @@ static int sf_launch_potrf_v1(double* A, int n, int lda, int64_t stride, int bat
 
 static std::atomic<int> g_chol_sequence{-1};
 int sf_set_cholesky_sequence(int mode) {
-    if (mode < -1 || mode > 1) {
-        sf_set_error("cholesky sequence: -1 automatic, 0 fused panel kernel, 1 unfused");
+    if (mode < -1 || mode > 2) {
+        sf_set_error("cholesky sequence: -1 automatic, 0 fused panel kernel, 1 unfused, 2 wide (panel pairs)");
         return SF_EINVAL;
     }
     g_chol_sequence.store(mode);
@@ -1846,7 +2293,8 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
     SF_TRY(sf_exec_event(ex, &e_fork));
     SF_HIP(hipEventRecord(e_fork, s));
     if (c != s) SF_HIP(hipStreamWaitEvent(c, e_fork, 0));
-    for (int g = 1; g < G; ++g) SF_HIP(hipStreamWaitEvent(gs[g], e_fork, 0));
+    for (int g = 0; g < G; ++g)
+        if (gs[g] != s) SF_HIP(hipStreamWaitEvent(gs[g], e_fork, 0));
 
     double* part = Wt2 + 2 * (size_t)batch * sW + 64;  // split-K partial sums: region 0 = chain, 1 + g = group g
     const int nt = (n + GT - 1) / GT;
@@ -1968,8 +2416,214 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
         SF_HIP(hipEventRecord(e_join, c));
         SF_HIP(hipStreamWaitEvent(s, e_join, 0));
     }
-    for (int g = 1; g < G; ++g)
-        if (e_rest[g]) SF_HIP(hipStreamWaitEvent(s, e_rest[g], 0));
+    for (int g = 0; g < G; ++g)
+        if (e_rest[g] && gs[g] != s) SF_HIP(hipStreamWaitEvent(s, e_rest[g], 0));
+    return SF_OK;
+}
+
+// Factorisation with the WIDE panel kernel: pairs of panels.  Per pair p (panels k = 2p, k + 1; columns [k0, k0 + 256)):
+//   chain(p)  on the side stream:  D(k) -> top(k): narrow k_chol_panel for slab k+1 (gives L21, parks tile (k+1, k+1))
+//             -> D(k+1);  depends on A(p-1) only
+//   A(p)      k_chol_panel_w for the slabs k+2, k+3 (the rows of the NEXT pair's diagonal block; parks tile (k+2, k+2)):
+//             one round of workgroups on its own stream, so that chain(p+1) runs beside B(p)
+//   B(p)      k_chol_panel_w for the slabs k+4 .. on the caller's stream
+// A trailing single panel (odd number of panels) and pairs without rows below them are narrow steps of the chain.
+// The four most recent inverse tiles W(k) live in the two 256-row buffers of the narrow sequence (slot k & 3).
+static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
+                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
+    if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
+        sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
+        return SF_EINVAL;
+    }
+    static sf_dev_once attr_once;
+    SF_CHECK(sf_once_per_device(&attr_once, []() -> int {
+        SF_HIP(hipFuncSetAttribute((const void*)k_chol_panel_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SF_HIP(hipFuncSetAttribute((const void*)k_chol_panel_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return SF_OK;
+    }));
+    double* T = work + (size_t)batch * SF_LTB_DOUBLES;
+    const int64_t sT = (int64_t)(n + SF_NB) * SF_LDT + SF_TSKEW;
+    double* Wt2 = T + (size_t)batch * sT;
+    const int64_t sW = (int64_t)SF_NB * SF_LDT + SF_TSKEW;
+    auto Wslot = [&](int k) { return Wt2 + (size_t)((k >> 1) & 1) * batch * sW + (size_t)(k & 1) * GT * SF_LDT; };
+    double* part = Wt2 + 2 * (size_t)batch * sW + 64;
+    SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
+    SF_TRY(sf_exec_prepare(ex));
+    hipStream_t c = ex->side, xa = ex->xa;
+    hipEvent_t e_fork;
+    SF_TRY(sf_exec_event(ex, &e_fork));
+    SF_HIP(hipEventRecord(e_fork, s));
+    SF_HIP(hipStreamWaitEvent(c, e_fork, 0));
+    SF_HIP(hipStreamWaitEvent(xa, e_fork, 0));
+    SF_HIP(hipStreamWaitEvent(ex->grp[0], e_fork, 0));
+    const int nt = (n + GT - 1) / GT;
+
+    auto narrow = [&](int k0, int pw, int row0, int nslab, const double* Wt, bool to_scratch, hipStream_t st) -> int {
+        sf_panel_args g = {};
+        g.C = A;
+        g.sC = stride;
+        g.lda = lda;
+        g.n = n;
+        g.k0 = k0;
+        g.pw = pw;
+        g.row0 = row0;
+        g.nslab = nslab;
+        g.slab_step = 1;
+        g.Wt = Wt;
+        g.sW = sW;
+        g.rhs = rhs;
+        g.ldr = ldr;
+        if (to_scratch) {
+            g.Sout = T;
+            g.sS = sT;
+            g.ldS = SF_LDT;
+        }
+        if (gen) {
+            g.genY = gen->Y;
+            g.sY = (int64_t)gen->mpad * gen->ldy;
+            g.ldy = gen->ldy;
+            g.mpad = gen->mpad;
+            g.tilemap = gen->tilemap;
+            g.nt128 = gen->nt128;
+        }
+        const long long nblk = (long long)nslab * batch;
+        double rows = 0.0;
+        for (int i = 0; i < nslab; ++i) rows += (n - (row0 + i * GT) < GT) ? n - (row0 + i * GT) : GT;
+        const double flops_main = 2.0 * k0 * rows * pw * batch;
+        const double flops_epi = (rows * pw * (double)pw + (double)GT * rows * pw) * batch;
+        const int nk = k0 / GK;
+        const int S = pw > 0 ? sf_split_policy(nblk, nk) : 1;
+        void* tok;
+        if (S > 1) {
+            g.ksplit = S;
+            g.kchunk = (nk + S - 1) / S;
+            g.part = part;
+            sf_prof_gemm_begin(st, flops_main, &tok);
+            hipLaunchKernelGGL((k_chol_panel<false, 1>), dim3((unsigned)(nblk * S)), dim3(512), 0, st, g);
+            sf_prof_gemm_end(tok);
+            sf_prof_gemm_begin(st, flops_epi, &tok);
+            if (rhs)
+                hipLaunchKernelGGL((k_chol_panel<true, 2>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+            else
+                hipLaunchKernelGGL((k_chol_panel<false, 2>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+            sf_prof_gemm_end(tok);
+        } else {
+            sf_prof_gemm_begin(st, flops_main + flops_epi, &tok);
+            if (rhs)
+                hipLaunchKernelGGL((k_chol_panel<true, 0>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+            else
+                hipLaunchKernelGGL((k_chol_panel<false, 0>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+            sf_prof_gemm_end(tok);
+        }
+        SF_LAUNCH_CHECK();
+        return SF_OK;
+    };
+    auto wide = [&](int k, int slab0, int nslab, int step, bool park, hipStream_t st) -> int {
+        sf_panelw_args g = {};
+        g.C = A;
+        g.sC = stride;
+        g.lda = lda;
+        g.n = n;
+        g.k0 = k * GT;
+        g.row0 = slab0 * GT;
+        g.nslab = nslab;
+        g.slab_step = step;
+        g.Wt0 = Wslot(k);
+        g.Wt1 = Wslot(k + 1);
+        g.sW = sW;
+        g.rhs = rhs;
+        g.ldr = ldr;
+        if (park) {
+            g.Sout = T;
+            g.sS = sT;
+            g.ldS = SF_LDT;
+        }
+        if (gen) {
+            g.genY = gen->Y;
+            g.sY = (int64_t)gen->mpad * gen->ldy;
+            g.ldy = gen->ldy;
+            g.mpad = gen->mpad;
+            g.tilemap = gen->tilemap;
+            g.nt128 = gen->nt128;
+        }
+        const long long nblk = (long long)nslab * batch;
+        if (nblk > 0x7fffffffLL) {
+            sf_set_error("panel grid too large");
+            return SF_EINVAL;
+        }
+        double rows = 0.0;
+        for (int i = 0; i < nslab; ++i) rows += (n - (slab0 + i * step) * GT < GT) ? n - (slab0 + i * step) * GT : GT;
+        // algorithmic flops of the two panel steps it replaces: update 2 k0 rows 128 (+ 128 more K for the second panel),
+        // solves rows 128^2 each, symmetric rank-128 updates of the lower tiles
+        const double flops = (2.0 * g.k0 * rows * GT + 2.0 * (g.k0 + GT) * rows * GT + 2.0 * (rows * GT * (double)GT + (double)GT * rows * GT)) * batch;
+        void* tok;
+        sf_prof_gemm_begin(st, flops, &tok);
+        if (rhs)
+            hipLaunchKernelGGL(k_chol_panel_w<true>, dim3((unsigned)nblk), dim3(1024), SF_PANELW_LDS, st, g);
+        else
+            hipLaunchKernelGGL(k_chol_panel_w<false>, dim3((unsigned)nblk), dim3(1024), SF_PANELW_LDS, st, g);
+        sf_prof_gemm_end(tok);
+        SF_LAUNCH_CHECK();
+        return SF_OK;
+    };
+    auto diag = [&](int k) -> int {
+        const int k0 = k * GT;
+        const int pw = (n - k0 < GT) ? n - k0 : GT;
+        return sf_launch_diag128(T, sT, pw, info, k0, rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wslot(k), sW,
+                                 batch, c);
+    };
+
+    SF_TRY(narrow(0, 0, 0, 1, nullptr, true, c));  // diagonal tile 0 goes to the scratch unchanged
+    // B(p) runs as two interleaved slab groups on two streams (like the narrow sequence): a group's next launch only
+    // needs its own previous one, so the last, partly filled round of one group overlaps the other group's work
+    hipStream_t bs[2] = {s, ex->grp[0]};
+    hipEvent_t e_A = nullptr;
+    hipEvent_t e_B[2] = {nullptr, nullptr}, e_Bprev[2] = {nullptr, nullptr};  // B(p-1), B(p-2) per group
+    for (int k = 0; k < nt; k += 2) {
+        // chain(p): needs the tile parked by A(p-1) and the rows of slab k+1 (A(p-1)); its W slots were last read by the
+        // wide launches two pairs ago
+        if (e_A) SF_HIP(hipStreamWaitEvent(c, e_A, 0));
+        for (int g = 0; g < 2; ++g)
+            if (e_Bprev[g]) SF_HIP(hipStreamWaitEvent(c, e_Bprev[g], 0));
+        SF_TRY(diag(k));
+        if (k + 1 >= nt) break;
+        SF_TRY(narrow(k * GT, GT, (k + 1) * GT, 1, Wslot(k), true, c));  // (k + 1 < nt: panel k is full)
+        SF_TRY(diag(k + 1));
+        if (k + 2 >= nt) break;  // no rows below the pair (a narrower last panel never has rows below it)
+        hipEvent_t e_chain;
+        SF_TRY(sf_exec_event(ex, &e_chain));
+        SF_HIP(hipEventRecord(e_chain, c));
+        // A(p): slabs k+2, k+3 -- needs chain(p) and the rows B(p-1) finished (the first slab of either group)
+        const int na = (nt - (k + 2) < 2) ? nt - (k + 2) : 2;
+        SF_HIP(hipStreamWaitEvent(xa, e_chain, 0));
+        for (int g = 0; g < 2; ++g)
+            if (e_B[g]) SF_HIP(hipStreamWaitEvent(xa, e_B[g], 0));
+        SF_TRY(wide(k, k + 2, na, 1, true, xa));
+        SF_TRY(sf_exec_event(ex, &e_A));
+        SF_HIP(hipEventRecord(e_A, xa));
+        // B(p): slabs k+4 .., slab k+4+g, k+6+g, ... in group g
+        for (int g = 0; g < 2; ++g) {
+            e_Bprev[g] = e_B[g];
+            e_B[g] = nullptr;
+            const int first = k + 4 + g;
+            if (first >= nt) continue;
+            const int cnt = (nt - 1 - first) / 2 + 1;
+            SF_HIP(hipStreamWaitEvent(bs[g], e_chain, 0));
+            // (group g of pair p continues the rows group g of pair p-1 left: k+4+g = (k-2)+4+g+2, same parity)
+            SF_TRY(wide(k, first, cnt, 2, false, bs[g]));
+            SF_TRY(sf_exec_event(ex, &e_B[g]));
+            SF_HIP(hipEventRecord(e_B[g], bs[g]));
+        }
+    }
+    hipEvent_t e_join;
+    SF_TRY(sf_exec_event(ex, &e_join));
+    SF_HIP(hipEventRecord(e_join, c));
+    SF_HIP(hipStreamWaitEvent(s, e_join, 0));
+    if (e_A) SF_HIP(hipStreamWaitEvent(s, e_A, 0));
+    for (int g = 0; g < 2; ++g) {
+        if (e_B[g] && bs[g] != s) SF_HIP(hipStreamWaitEvent(s, e_B[g], 0));
+        if (e_Bprev[g] && bs[g] != s) SF_HIP(hipStreamWaitEvent(s, e_Bprev[g], 0));
+    }
     return SF_OK;
 }
 
@@ -2106,8 +2760,16 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     // B = 128: 55.3 vs 50.4.
     static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");  // tuning aid: "1" always unfused, "0" always fused
     const int sel = g_chol_sequence.load();                 // sf_debug_cholesky_sequence(): tests drive both
-    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] != '0' : batch < 28);
+    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < 28);
+    // The wide sequence (panel pairs, one 16-wave workgroup per CU) halves the A-operand stream and a third of all HBM
+    // traffic of the factorisation; the chip is power-bound at full batches, so the clock it sustains rises by ~4 % --
+    // but one workgroup per CU has nothing to overlap its epilogue and barriers with.  Measured (bench.py, same box):
+    // cfg 2 (N = 4096, B = 128) 0.5-1 % faster, cfg 3 (1600 units of N = 3008) equal, cfg 5 (N = 16384, B = 32) 2.4 %
+    // slower, B <= 64 slower -> taken only for full batches of mid-size matrices.
+    const bool wide_auto = batch >= 96 && batch <= 512 && n >= 2048 && n <= 8192;
+    const bool v3 = sel >= 0 ? sel == 2 : (force ? force[0] == '2' : wide_auto);
     if (!ex) ex = sf_exec_thread_local();
+    if (v3) return sf_launch_potrf_v3(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
     return v1 ? sf_launch_potrf_v1(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex)
               : sf_launch_potrf_v2(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
 }

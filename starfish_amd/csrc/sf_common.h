@@ -77,11 +77,15 @@ static inline int sf_once_per_device(sf_dev_once* once, F&& setup) {
 // Streams and events a launch sequence needs besides the caller's stream.  Owned by a context (sf_ctx) or,
 // for the context-free entry points, by the calling thread -- the library keeps no process-global stream state,
 // so contexts can be driven from different host threads (and devices) concurrently.
-#define SF_EXEC_GROUPS 2  // streams the slab groups of the fused Cholesky are spread over (the caller's + 1; measured: 1 -> 54.8, 2 -> 52.9, 3 -> 53.8 ms at cfg 2)
+#ifndef SF_EXEC_GROUPS
+#define SF_EXEC_GROUPS 2
+#endif
+// streams the slab groups of the fused Cholesky are spread over (the caller's + 1; measured: 1 -> 54.8, 2 -> 52.9, 3 -> 53.8 ms at cfg 2)
 struct sf_exec {
     int device = -1;
     hipStream_t side = nullptr;  // highest priority: the diagonal-block chain of the Cholesky
     hipStream_t grp[SF_EXEC_GROUPS - 1] = {};  // slab groups 1.. of the fused Cholesky (group 0 = caller's stream)
+    hipStream_t xa = nullptr;    // wide sequence: the launches the next pair's chain waits for (slabs k+2, k+3)
     hipStream_t aux = nullptr;   // banded path: band fill beside the transforms; multi-order calls: the fills
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t* pool = nullptr;

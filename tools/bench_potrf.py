@@ -1,5 +1,5 @@
 """Stand-alone timing of sf_potrf_batch on synthetic SPD matrices (kernel tuning aid).
-    python tools/bench_potrf.py [N] [B] [reps]"""
+    python tools/bench_potrf.py [N] [B] [reps] [sequence]"""
 import ctypes as C
 import os
 import sys
@@ -16,6 +16,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 lib = _lib.require_gpu()
+if len(sys.argv) > 4:  # launch sequence: 0 fused (128-column panels), 1 unfused, 2 wide (panel pairs)
+    assert lib.sf_debug_cholesky_sequence(int(sys.argv[4])) == 0
 dev = D.device_of()
 lda = N + 16
 # diagonally dominant random symmetric matrix generated on the device (plumbing only)

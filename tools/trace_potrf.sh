@@ -6,7 +6,7 @@ for kv in "$@"; do export "$kv"; done
 # the environment switches exist only in the tuning build (make -C starfish_amd/csrc TUNING=1 on the authoring box)
 [ -f $R/starfish_amd/libstarfish_amd_tuning.so ] && export SF_LIB_PATH=$R/starfish_amd/libstarfish_amd_tuning.so
 rm -rf $R/gpurun_out/trace_potrf
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_potrf -- python $R/tools/bench_potrf.py $NN $BB 1 > $R/gpurun_out/trace_potrf.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_potrf -- python $R/tools/bench_potrf.py $NN $BB 1 $SEQ > $R/gpurun_out/trace_potrf.log 2>&1
 grep "potrf " $R/gpurun_out/trace_potrf.log
 python - <<'PY'
 import csv, glob, os
