@@ -198,3 +198,25 @@ def test_extinct_ccm89_unpinned_law(gpu):
                                    rtol=1e-13)
         v = T.extinct(np.array([5494.5, 5500.0]), np.ones(2), 1.0, Rv=3.1, law=law)
         assert abs(-2.5 * np.log10(v[1]) - 1.0) < 2e-3
+
+
+def test_extinct_kernels_reproduce_the_papers_tables(gpu):
+    """The DEVICE laws against numbers printed in the papers (no oracle in between): Fitzpatrick (1999) Table 3,
+    Calzetti et al. (2000) eq. 4 by hand, Fitzpatrick & Massa (2007) anchors, CCM89 Table 3.  extinct() stays
+    parity-unpinned (third-party `extinction` absent); this is the strongest pin available."""
+    from starfish_amd import transforms as T
+
+    def a_lambda(w, law, **kw):  # A_lambda / Av through the kernel
+        w = np.asarray(w, dtype=float)
+        return -2.5 * np.log10(T.extinct(w, np.ones_like(w), 1.0, law=law, **kw))
+
+    lam = np.array([26500.0, 12200.0, 6000.0, 5470.0, 4670.0, 4110.0, 2700.0, 2600.0])
+    np.testing.assert_allclose(3.1 * a_lambda(lam, "fitzpatrick99", Rv=3.1),
+                               [0.265, 0.829, 2.688, 3.055, 3.806, 4.315, 6.265, 6.591], atol=1.5e-3)
+    np.testing.assert_allclose(4.05 * a_lambda([5500.0, 22000.0, 1200.0], "calzetti00", Rv=4.05), [4.05, 0.3692, 12.119], atol=5e-3)
+    np.testing.assert_allclose(3.1 * (a_lambda([5530.0, 4000.0, 3300.0], "fm07") - 1.0), [0.0, 1.322, 2.055], atol=1e-9)
+    band_x = np.array([2.78, 1.82, 1.43, 1.11, 0.80])  # U V R I J of CCM89 Table 3 (Rv = 3.1)
+    np.testing.assert_allclose(a_lambda(1e4 / band_x, "ccm89", Rv=3.1), [1.569, 1.000, 0.751, 0.479, 0.282], atol=1.5e-3)
+    a1 = 1 + 0.104 - 0.609 + 0.701 + 1.137 - 1.718 - 0.827 + 1.647 - 0.505  # O'Donnell (1994) coefficient sums at y = 1
+    b1 = 1.952 + 2.908 - 3.989 - 7.985 + 11.102 + 5.491 - 10.805 + 3.347
+    np.testing.assert_allclose(a_lambda([1e4 / 2.82, 1e4 / 1.82], "odonnell94", Rv=3.1), [a1 + b1 / 3.1, 1.0], atol=1e-12)

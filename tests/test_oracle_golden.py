@@ -163,3 +163,51 @@ def test_oracle_matches_reference_cfg3_orders():
         got = O.log_likelihood(oo, synth.shared_to_oracle_params(orders[o], g["P"][0]))
         want = g["lnl"][o, 0]
         assert abs(got - want) <= 1e-8 * abs(want) + 1e-8, (o, got, want)
+
+
+def test_extinction_laws_against_the_papers_own_numbers():
+    """extinct() stays parity-UNPINNED (no `extinction` package in either interpreter), so all five laws are at
+    least held to numbers printed in the papers themselves, worked out here by hand -- independent of the oracle's
+    code path: Fitzpatrick (1999) Table 3 anchors, Calzetti et al. (2000) eq. 4 at tabulated wavelengths, the
+    O'Donnell (1994) polynomial at y = 0 and y = 1, Fitzpatrick & Massa (2007) spline anchors."""
+    # --- Fitzpatrick 1999, Table 3 (Rv = 3.1): A(lambda)/E(B-V) at the spline anchors
+    lam = np.array([26500.0, 12200.0, 6000.0, 5470.0, 4670.0, 4110.0, 2700.0, 2600.0])
+    table3 = np.array([0.265, 0.829, 2.688, 3.055, 3.806, 4.315, 6.265, 6.591])
+    got = 3.1 * O.fitzpatrick99_a_lambda(lam, 1.0, 3.1)
+    np.testing.assert_allclose(got, table3, atol=1.5e-3)
+    # E(B-V) normalisation: A(4400) - A(5500) = Av / Rv to a few per cent (the curve is normalised for the broad-band
+    # filters, not for these monochromatic wavelengths)
+    d = np.diff(O.fitzpatrick99_a_lambda([5500.0, 4400.0], 1.0, 3.1))[0]
+    assert abs(d * 3.1 - 1.0) < 0.05
+    # the Rv dependence of the optical anchors (his Table 4 polynomials) at Rv = 5: 6000 A -> -0.422809 + 1.00270 Rv + 2.13572e-4 Rv^2
+    want = (-0.422809 + 1.00270 * 5.0 + 2.13572e-4 * 25.0) / 5.0
+    assert abs(O.fitzpatrick99_a_lambda([6000.0], 1.0, 5.0)[0] - want) < 1e-6
+
+    # --- Calzetti et al. 2000, eq. 4 (Rv = 4.05): k(lambda) by hand
+    k = lambda w: 4.05 * O.calzetti00_a_lambda(np.atleast_1d(float(w)), 1.0, 4.05)[0]  # noqa: E731
+    assert abs(k(5500.0) - 4.05) < 3e-3          # k(V) = Rv: 2.659 (-2.156 + 1.509/0.55 - 0.198/0.55^2 + 0.011/0.55^3) + 4.05
+    assert abs(k(22000.0) - 0.3692) < 1e-3       # 2.659 (-1.857 + 1.040/2.2) + 4.05
+    assert abs(k(1200.0) - 12.119) < 5e-3        # 2.659 (-2.156 + 1.509/0.12 - 0.198/0.12^2 + 0.011/0.12^3) + 4.05
+    assert abs(k(6300.0 - 1e-6) - 3.47663) < 1e-4 and abs(k(6300.0) - 3.50170) < 1e-4  # the paper's two branches at 0.63 um
+
+    # --- O'Donnell 1994: a(y), b(y) for 1.1 <= x <= 3.3; y = x - 1.82
+    assert O.odonnell94_a_lambda([1e4 / 1.82], 1.0, 3.1)[0] == 1.0      # y = 0: a = 1, b = 0
+    a1 = 1 + 0.104 - 0.609 + 0.701 + 1.137 - 1.718 - 0.827 + 1.647 - 0.505    # y = 1: the coefficient sums
+    b1 = 1.952 + 2.908 - 3.989 - 7.985 + 11.102 + 5.491 - 10.805 + 3.347
+    for rv in (3.1, 4.5):
+        assert abs(O.odonnell94_a_lambda([1e4 / 2.82], 1.0, rv)[0] - (a1 + b1 / rv)) < 1e-12
+    x = np.linspace(1.1, 3.3, 45)
+    assert np.max(np.abs(O.odonnell94_a_lambda(1e4 / x, 1.0) - O.ccm89_a_lambda(1e4 / x, 1.0))) < 0.06  # a refit of the same data: within 3 % of CCM89
+    np.testing.assert_array_equal(O.odonnell94_a_lambda([2000.0, 20000.0], 1.3, 2.9), O.ccm89_a_lambda([2000.0, 20000.0], 1.3, 2.9))
+
+    # --- Fitzpatrick & Massa 2007 (Rv = 3.1): optical spline anchors E(lambda - V)/E(B-V) = 0, 1.322, 2.055 at 5530, 4000, 3300 A;
+    #     infrared power law k = (-0.83 + 0.63 Rv) x^1.84 - Rv
+    got = 3.1 * (O.fm07_a_lambda([5530.0, 4000.0, 3300.0], 1.0) - 1.0)
+    np.testing.assert_allclose(got, [0.0, 1.322, 2.055], atol=1e-12)
+    for xx in (0.25, 0.5, 0.75, 1.0):
+        want = 1 + ((-0.83 + 0.63 * 3.1) * xx**1.84 - 3.1) / 3.1
+        assert abs(O.fm07_a_lambda([1e4 / xx], 1.0)[0] - want) < 1e-12
+    # ultraviolet: the FM90 parametrisation with the paper's mean coefficients, evaluated by hand at x = 5 um^-1
+    xx = 5.0
+    kuv = -0.175 + 0.807 * xx + 2.991 * xx**2 / ((xx**2 - 4.592**2) ** 2 + xx**2 * 0.922**2)
+    assert abs(O.fm07_a_lambda([2000.0], 1.0)[0] - (1 + kuv / 3.1)) < 1e-12

@@ -1,11 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3n
-(time python -m pytest tests -m gpu -x -q --durations=8) > gpurun_out/r3n/tests.log 2>&1; tail -16 gpurun_out/r3n/tests.log
-python bench.py > gpurun_out/r3n/bench_default.json 2> gpurun_out/r3n/bench_default.err; tail -c 300 gpurun_out/r3n/bench_default.err
-python -c "
-import json
-d=json.loads([l for l in open('gpurun_out/r3n/bench_default.json') if l.startswith('{')][0])
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['sustained_clock_mhz'])
-print([ (r['batch'], round(r['value']), round(r['per_eval_efficiency_vs_full_batch'],3)) for r in d['strong_scaling_proxy']['rows']])
-print({k:(round(v['value'],1), round(v['ms_per_step'],1), round(v['roofline']['frac'],3)) for k,v in d['other_configs'].items()})
-"
+bash tools/profile_bench.sh r03_a_cfg2 --config cfg2 > gpurun_out/r03_a_cfg2.log 2>&1
+SF_LIB_PATH=$GRAFT_REPO_ROOT/starfish_amd/libstarfish_amd_tuning.so SF_CHOL_UNFUSED=0 bash tools/profile_bench.sh r03_a_cfg2_narrow --config cfg2 > gpurun_out/r03_a_cfg2_narrow.log 2>&1
+bash tools/profile_bench.sh r03_a_cfg3 --config cfg3 --steps 2 > gpurun_out/r03_a_cfg3.log 2>&1
+tail -3 gpurun_out/r03_a_cfg2.log gpurun_out/r03_a_cfg2_narrow.log gpurun_out/r03_a_cfg3.log
+ls gpurun_out/
