@@ -234,6 +234,17 @@ int sf_forward_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const doubl
                      double* d_flux, double* d_cov, double* d_log_scale, int* d_info,
                      void* d_work, size_t work_bytes, void* stream);
 
+/* The fused covariance fill on its own: C = X^T Sigma_w^-1 X (spectrum_model.py:334-338) + sigma^2 on
+ * the diagonal (:338) + global Matern-3/2 kernel + local Gaussian kernels (models/kernels.py:7-81), and -- with
+ * add_jitter -- the 1e-10 the likelihood adds before factorising (spectrum_model.py:399), in the reference's order of
+ * additions, written in ONE pass into the caller's array: matrix b at d_cov + b * stride, row stride ld >= n.
+ * lower_only: tiles above the diagonal are skipped (entries above the diagonal INSIDE a diagonal tile may be written; a
+ * factorisation never reads them).  (sf_forward_batch = this with ld = n, both triangles, no
+ * jitter, plus the flux; the likelihood entry points run the same kernel on the workspace matrices.) */
+int sf_cov_fill_batch(sf_ctx* ctx, const sf_model_desc* model, int B, const double* d_params, double* d_cov, int ld,
+                      int64_t stride, int lower_only, int add_jitter, int* d_info, void* d_work, size_t work_bytes,
+                      void* stream);
+
 /* SpectrumModel.log_likelihood without the prior term (spectrum_model.py:397-405):
  * d_lnl[B] = -(logdet + sqmah)/2; optional d_logdet[B], d_sqmah[B], d_resid[B*n],
  * d_log_scale[B].  Items with d_info[b] != 0 get lnl = -inf. */

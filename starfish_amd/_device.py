@@ -507,6 +507,24 @@ class DeviceOrder:
                 info=info.cpu().numpy(),
             )
 
+    def cov_fill(self, md, params, ld=None, lower_only=False, add_jitter=False):
+        """The fused covariance fill alone (sf_cov_fill_batch): (B, n, ld) array, row stride ``ld`` >= n (columns
+        beyond n are left as allocated: zero here)."""
+        torch = _torch()
+        with torch.cuda.device(self.dev):
+            P = params if torch.is_tensor(params) else to_dev(params, self.dev)
+            B = int(P.shape[0])
+            ld = int(ld or self.n)
+            cov = torch.zeros((B, self.n, ld), dtype=torch.float64, device=self.dev)
+            info = empty((B,), self.dev, torch.int32)
+            ws = self._work(md, B)
+            rc = self.lib.sf_cov_fill_batch(
+                self.ctx, C.byref(md), B, ptr(P), ptr(cov), ld, self.n * ld, int(lower_only), int(add_jitter), ptr(info),
+                ptr(ws), ws.numel(), stream_ptr(self.dev),
+            )
+            _lib.check(rc, "sf_cov_fill_batch")
+            return cov.cpu().numpy(), info.cpu().numpy()
+
     def transform(self, md, params):
         torch = _torch()
         with torch.cuda.device(self.dev):

@@ -114,6 +114,10 @@ SIGNATURES = {
         C.c_int,
         [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],
     ),
+    "sf_cov_fill_batch": (
+        C.c_int,
+        [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, C.c_int, C.c_int64, C.c_int, C.c_int, _VP, _VP, C.c_size_t, _VP],
+    ),
     "sf_emulator_joint_batch": (
         C.c_int,
         [_VP, C.POINTER(ModelDesc), C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP],

@@ -964,6 +964,32 @@ extern "C" int sf_forward_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
     return SF_OK;
 }
 
+extern "C" int sf_cov_fill_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params, double* d_cov, int ld,
+                                 int64_t stride, int lower_only, int add_jitter, int* d_info, void* d_work, size_t work_bytes,
+                                 void* stream) {
+    int rc = check_work(c, mdl, B, d_work, work_bytes, false);
+    if (rc) return rc;
+    if (!d_cov || ld < c->n || stride < (int64_t)c->n * ld) {
+        sf_set_error("sf_cov_fill_batch: d_cov required, ld >= n (%d), stride >= n * ld", c->n);
+        return SF_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    Work w = carve(c, mdl, B, d_work, work_bytes, false);
+    // (the rank-m term needs Y = L_w^-1 (Omega X): the transform chain and the emulator query run first)
+    rc = run_transforms(c, mdl, B, d_params, w, nullptr, nullptr, nullptr, nullptr, true, s);
+    if (rc) return rc;
+    sf_fill_args f = fill_args(c, mdl, d_params, w);
+    f.C = d_cov;
+    f.lda = ld;
+    f.stride = stride;
+    f.lower_only = lower_only ? 1 : 0;
+    f.add_jitter = add_jitter ? 1 : 0;
+    rc = sf_launch_fill(f, B, s);
+    if (rc) return rc;
+    if (d_info) SF_HIP(hipMemcpyAsync(d_info, w.info_e, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return SF_OK;
+}
+
 extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params,
                                 double* d_lnl, double* d_logdet, double* d_sqmah, double* d_resid,
                                 double* d_log_scale, int* d_info, void* d_work, size_t work_bytes,

@@ -280,3 +280,31 @@ def test_full_size_properties_permutation_and_null_kernel(chol_sequence):
         g = do.loglike(md2, rows2, solver=solver)
         assert (g["info"] == 0).all()
         np.testing.assert_allclose(g["lnl"], base["lnl"], rtol=1e-13)
+
+
+def test_cov_fill_entry_point_matches_forward_and_reference():
+    """sf_cov_fill_batch (a3 + a4 + a14 + a15 fused, on its own): the same matrix as SpectrumModel.__call__
+    (reference golden), into a caller-chosen layout (padded rows, lower triangle only) and with the likelihood's
+    1e-10 jitter on request."""
+    g = load_golden("model_small.npz")
+    o = synth.make_order(N=256, m=4, seed=5)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    p = small_params(o, "full", g["factors"])
+    md, rows = pack_rows(do, [p, p])
+    fw = do.forward(md, rows)["cov"][0]
+    full, info = do.cov_fill(md, rows)
+    assert (info == 0).all() and full.shape == (2, 256, 256)
+    np.testing.assert_array_equal(full[0], fw)            # the same kernel, the same bits
+    np.testing.assert_array_equal(full[0], full[1])
+    np.testing.assert_allclose(full[0], g["full_cov"], rtol=1e-10, atol=1e-11 * np.abs(g["full_cov"]).max())
+    padded, _ = do.cov_fill(md, rows[:1], ld=272, lower_only=True, add_jitter=True)
+    assert padded.shape == (1, 256, 272)
+    lo = np.tril_indices(256)
+    want = fw.copy()
+    want[np.diag_indices(256)] += 1e-10                   # spectrum_model.py:399
+    np.testing.assert_array_equal(padded[0][:, :256][lo], want[lo])
+    # untouched: the padding columns and everything a whole tile above the diagonal (inside the tiles on the diagonal
+    # the upper part may be written -- the factorisation never reads it)
+    ii, jj = np.triu_indices(256, 128)
+    assert not padded[0][:, 256:].any() and not padded[0][:, :256][ii, jj].any()
