@@ -1599,8 +1599,8 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
 //   2b T2 -= L1 L21^T         (L21 = L[panel k+1 rows, panel k columns], left in place by the chain's narrow step)
 //   2c L2 = T2 W_k+1
 //   3  L -> C in place, rhs[slab] -= L1 z_k + L2 z_k+1
-//   4  S  = C[slab, slab] - L L^T (K = 256): waves 0-7 take the columns of panel k, waves 8-15 those of panel k+1 in the
-//         36-blocks-on-8-waves layout of k_chol_panel; the two halves are added through LDS in fixed order
+//   4  S  = C[slab, slab] - L L^T (K = 256): L goes from the accumulators into one 128 x 128 LDS image per panel; the 36
+//         lower blocks of the tile are spread over the 16 waves (9 per SIMD) and accumulate over both panels in registers
 // Same arithmetic as two consecutive k_chol_panel steps; the summation order of 2b differs (natural k order instead
 // of the K-permuted fragments), so results agree to rounding, not bit for bit.
 #define WST (3 * GT * GK)  // doubles per LDS stage: A 128 x 16, B 256 x 16
@@ -1922,89 +1922,66 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
     }
 
     // ---------------------------------------------------------------- 4: S = C[slab, slab] - L L^T, K = 256
+    // L is taken from the accumulators through ONE LDS image per panel (Ts, 128 x 128, row stride 130: the operand reads of
+    // a wave instruction hit distinct 8-byte banks per half wave), not read back from global memory: the 36 lower blocks
+    // of the tile are spread 9 per SIMD (3 + 2 + 2 + 2 over its waves: block t = wm + 4 (wn + 4 j) of the row-major
+    // lower-triangular enumeration) and accumulate over both panels in registers -- four barriers, no K-slab staging loop,
+    // no cross-wave reduction.
     {
-        const int hg = w >> 3, w8 = w & 7;  // K half (panel) and position in the 8-wave block layout
-        const int p = w8 >> 1, h = w8 & 1;
-        int bi[5], bj[5];
+        constexpr int TLD = 130;
+        double* Ts = smw;
+        const int nsb = wn == 0 ? 3 : 2;
+        int sbi[3], sbj[3];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            if (h == 0) {
-                bi[q] = 7 - p;
-                bj[q] = q;
-            } else {
-                const int n_hi = 3 - p;  // blocks 5 .. 7-p of row 7-p, then blocks 0 .. p of row p
-                const int qq = q < 4 ? q : 0;
-                bi[q] = qq < n_hi ? 7 - p : p;
-                bj[q] = qq < n_hi ? 5 + qq : qq - n_hi;
-            }
+        for (int j = 0; j < 3; ++j) {
+            const int t = min(wm + 4 * (wn + 4 * j), 35);
+            int bi = 0;
+            while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+            sbi[j] = bi;
+            sbj[j] = t - bi * (bi + 1) / 2;
         }
-        const int nstore = h == 0 ? 5 : 4;
-        const int t5 = tid & 511;
-        const int lr2 = t5 >> 3, lc2 = (t5 & 7) * 2;
-        double* As2 = smw + hg * (2 * GT * GLD);  // [2][128][GLD] per K half
-        const double* Lp[2];
+        sf_d4 acc2[3];
+        {
+            const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) Lp[q] = Cb + (int64_t)(row0 + min(lr2 + 64 * q, rows_here - 1)) * g.lda + k0 + hg * GT + lc2;
-        double2 rl[2];
-        auto gload2 = [&](int kt) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) rl[q] = *(const double2*)(Lp[q] + kt * GK);
-        };
-        auto lstore2 = [&](int buf) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                double* pa = As2 + buf * (GT * GLD) + (lr2 + 64 * q) * GLD + lc2;
-                pa[0] = rl[q].x;
-                pa[1] = rl[q].y;
-            }
-        };
-        __syncthreads();  // the L slab is visible to every wave of the workgroup; the LDS buffers are free
-        gload2(0);
-        const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
-        sf_d4 acc2[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
-                acc2[q][r] = (hg == 0 && q < nstore && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
-            }
-        lstore2(0);
-        __syncthreads();
-        constexpr int nk2 = GT / GK;
-        for (int kt = 0; kt < nk2; ++kt) {
-            if (kt + 1 < nk2) gload2(kt + 1);
-            const double* S = As2 + (kt & 1) * (GT * GLD) + l15 * GLD + lq;
-#pragma unroll
-            for (int ks = 0; ks < GK / 4; ++ks) {
-#pragma unroll
-                for (int q = 0; q < 5; ++q)
-                    acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[bi[q] * 16 * GLD + ks * 4], S[bj[q] * 16 * GLD + ks * 4],
-                                                                   acc2[q], 0, 0, 1);  // neg:[1,0,0]
-            }
-            if (kt + 1 < nk2) lstore2((kt & 1) ^ 1);
-            __syncthreads();
-        }
-        // the panel k + 1 half goes through LDS and is added by the panel k half (fixed order: deterministic)
-        double* Rd = smw + (w8 * 5) * 256 + lane * 4;
-        if (hg == 1) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) *(sf_d4*)(Rd + q * 256) = acc2[q];
-        }
-        __syncthreads();
-        if (hg == 0) {
-            const bool parked = g.Sout && sl == 0;
-            double* So = parked ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
-            const int ldo = parked ? g.ldS : g.lda;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                if (q >= nstore) continue;
-                const sf_d4 o = *(const sf_d4*)(Rd + q * 256);
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
-                    if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[q][r] + o[r];
+                    const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
+                    acc2[j][r] = (j < nsb && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
                 }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();  // the previous contents of the LDS image are dead
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Ts[(wm * 32 + mi * 16 + lq + 4 * r) * TLD + wn * 32 + nn * 16 + l15] = acc[mi][2 * half + nn][r];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j >= nsb) continue;
+                const double* Pa = Ts + (sbi[j] * 16 + l15) * TLD + lq;
+                const double* Pb = Ts + (sbj[j] * 16 + l15) * TLD + lq;
+#pragma unroll 8
+                for (int ks = 0; ks < GT / 4; ++ks)
+                    acc2[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[ks * 4], Pb[ks * 4], acc2[j], 0, 0, 1);  // neg:[1,0,0]
+            }
+        }
+        const bool parked = g.Sout && sl == 0;  // (only the first slab of a launch is the next diagonal tile)
+        double* So = parked ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
+        const int ldo = parked ? g.ldS : g.lda;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= nsb) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
+                if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[j][r];
             }
         }
     }
@@ -2254,8 +2231,8 @@ static int sf_launch_potrf_v1(double* A, int n, int lda, int64_t stride, int bat
 
 static std::atomic<int> g_chol_sequence{-1};
 int sf_set_cholesky_sequence(int mode) {
-    if (mode < -1 || mode > 2) {
-        sf_set_error("cholesky sequence: -1 automatic, 0 fused panel kernel, 1 unfused, 2 wide (panel pairs)");
+    if (mode < -1 || mode > 3) {
+        sf_set_error("cholesky sequence: -1 automatic, 0 fused panel kernel, 1 unfused, 2 wide (panel pairs), 3 wide then narrow (test aid)");
         return SF_EINVAL;
     }
     g_chol_sequence.store(mode);
@@ -2429,8 +2406,10 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
 //   B(p)      k_chol_panel_w for the slabs k+4 .. on the caller's stream
 // A trailing single panel (odd number of panels) and pairs without rows below them are narrow steps of the chain.
 // The four most recent inverse tiles W(k) live in the two 256-row buffers of the narrow sequence (slot k & 3).
+// tail_rounds: the pairs whose wide launches have at most this many rounds of workgroups left (and everything after them)
+// are single narrow steps; -1 = wide to the end; -2 = switch half-way (test aid: exercises the hand-over on any size).
 static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
-                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
+                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex, int tail_rounds) {
     if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
         sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
         return SF_EINVAL;
@@ -2458,7 +2437,8 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
     SF_HIP(hipStreamWaitEvent(ex->grp[0], e_fork, 0));
     const int nt = (n + GT - 1) / GT;
 
-    auto narrow = [&](int k0, int pw, int row0, int nslab, const double* Wt, bool to_scratch, hipStream_t st) -> int {
+    auto narrow = [&](int k0, int pw, int row0, int nslab, int step, const double* Wt, bool to_scratch, hipStream_t st,
+                      int region) -> int {
         sf_panel_args g = {};
         g.C = A;
         g.sC = stride;
@@ -2468,7 +2448,7 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         g.pw = pw;
         g.row0 = row0;
         g.nslab = nslab;
-        g.slab_step = 1;
+        g.slab_step = step;
         g.Wt = Wt;
         g.sW = sW;
         g.rhs = rhs;
@@ -2488,7 +2468,7 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         }
         const long long nblk = (long long)nslab * batch;
         double rows = 0.0;
-        for (int i = 0; i < nslab; ++i) rows += (n - (row0 + i * GT) < GT) ? n - (row0 + i * GT) : GT;
+        for (int i = 0; i < nslab; ++i) rows += (n - (row0 + i * step * GT) < GT) ? n - (row0 + i * step * GT) : GT;
         const double flops_main = 2.0 * k0 * rows * pw * batch;
         const double flops_epi = (rows * pw * (double)pw + (double)GT * rows * pw) * batch;
         const int nk = k0 / GK;
@@ -2497,7 +2477,7 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         if (S > 1) {
             g.ksplit = S;
             g.kchunk = (nk + S - 1) / S;
-            g.part = part;
+            g.part = part + (size_t)region * sf_split_region_tiles() * (GT * GT);
             sf_prof_gemm_begin(st, flops_main, &tok);
             hipLaunchKernelGGL((k_chol_panel<false, 1>), dim3((unsigned)(nblk * S)), dim3(512), 0, st, g);
             sf_prof_gemm_end(tok);
@@ -2573,23 +2553,36 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
                                  batch, c);
     };
 
-    SF_TRY(narrow(0, 0, 0, 1, nullptr, true, c));  // diagonal tile 0 goes to the scratch unchanged
+    SF_TRY(narrow(0, 0, 0, 1, 1, nullptr, true, c, 0));  // diagonal tile 0 goes to the scratch unchanged
     // B(p) runs as two interleaved slab groups on two streams (like the narrow sequence): a group's next launch only
-    // needs its own previous one, so the last, partly filled round of one group overlaps the other group's work
+    // needs its own previous one, so the last, partly filled round of one group overlaps the other group's work.
+    // Group g = slabs of parity g (k even: k+4+g, k+6+g, ...), in the wide pairs and in the narrow tail alike.
     hipStream_t bs[2] = {s, ex->grp[0]};
     hipEvent_t e_A = nullptr;
-    hipEvent_t e_B[2] = {nullptr, nullptr}, e_Bprev[2] = {nullptr, nullptr};  // B(p-1), B(p-2) per group
-    for (int k = 0; k < nt; k += 2) {
-        // chain(p): needs the tile parked by A(p-1) and the rows of slab k+1 (A(p-1)); its W slots were last read by the
-        // wide launches two pairs ago
+    hipEvent_t e_last[2] = {nullptr, nullptr};        // last launch of either group
+    std::vector<hipEvent_t> readers[4];               // launches that read W slot j (a D step may only overwrite it after them)
+    auto wait_readers = [&](int slot) -> int {
+        for (hipEvent_t e : readers[slot]) SF_HIP(hipStreamWaitEvent(c, e, 0));
+        readers[slot].clear();
+        return SF_OK;
+    };
+    // The narrow loop below finishes what the pairs leave (a trailing single panel, the last diagonal block) and can
+    // take over earlier (`tail_rounds`): the timeline suggested that the last pairs -- few rounds of ~1 ms workgroups,
+    // every dependency of the chain costs a round -- would be better off as narrow steps, the measurement says no
+    // (cfg 2: wide to the end 49.3 ms, hand-over with 2 / 5 / 8 / 12 rounds left 50.0 / 50.4 / 51.0 / 51.8, narrow 51.5).
+    int k = 0;
+    for (; k < nt; k += 2) {
+        if (k + 2 >= nt) break;  // no rows below the pair: the narrow loop finishes the diagonal block
+        const long long rounds_left = (long long)batch * (nt - (k + 4) > 0 ? nt - (k + 4) : 0) / 256;
+        if (tail_rounds >= 0 && rounds_left <= tail_rounds) break;  // -> narrow tail from panel k
+        if (tail_rounds == -2 && k >= (nt / 4) * 2 && k > 0) break;
+        // chain(p): needs the tile parked by A(p-1) and the rows of slab k+1 (A(p-1))
         if (e_A) SF_HIP(hipStreamWaitEvent(c, e_A, 0));
-        for (int g = 0; g < 2; ++g)
-            if (e_Bprev[g]) SF_HIP(hipStreamWaitEvent(c, e_Bprev[g], 0));
+        SF_TRY(wait_readers(k & 3));
         SF_TRY(diag(k));
-        if (k + 1 >= nt) break;
-        SF_TRY(narrow(k * GT, GT, (k + 1) * GT, 1, Wslot(k), true, c));  // (k + 1 < nt: panel k is full)
+        SF_TRY(narrow(k * GT, GT, (k + 1) * GT, 1, 1, Wslot(k), true, c, 0));  // (rows below the pair exist: panel k is full)
+        SF_TRY(wait_readers((k + 1) & 3));
         SF_TRY(diag(k + 1));
-        if (k + 2 >= nt) break;  // no rows below the pair (a narrower last panel never has rows below it)
         hipEvent_t e_chain;
         SF_TRY(sf_exec_event(ex, &e_chain));
         SF_HIP(hipEventRecord(e_chain, c));
@@ -2597,22 +2590,53 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         const int na = (nt - (k + 2) < 2) ? nt - (k + 2) : 2;
         SF_HIP(hipStreamWaitEvent(xa, e_chain, 0));
         for (int g = 0; g < 2; ++g)
-            if (e_B[g]) SF_HIP(hipStreamWaitEvent(xa, e_B[g], 0));
+            if (e_last[g]) SF_HIP(hipStreamWaitEvent(xa, e_last[g], 0));
         SF_TRY(wide(k, k + 2, na, 1, true, xa));
         SF_TRY(sf_exec_event(ex, &e_A));
         SF_HIP(hipEventRecord(e_A, xa));
+        readers[k & 3].push_back(e_A);
+        readers[(k + 1) & 3].push_back(e_A);
         // B(p): slabs k+4 .., slab k+4+g, k+6+g, ... in group g
         for (int g = 0; g < 2; ++g) {
-            e_Bprev[g] = e_B[g];
-            e_B[g] = nullptr;
             const int first = k + 4 + g;
             if (first >= nt) continue;
             const int cnt = (nt - 1 - first) / 2 + 1;
             SF_HIP(hipStreamWaitEvent(bs[g], e_chain, 0));
-            // (group g of pair p continues the rows group g of pair p-1 left: k+4+g = (k-2)+4+g+2, same parity)
             SF_TRY(wide(k, first, cnt, 2, false, bs[g]));
-            SF_TRY(sf_exec_event(ex, &e_B[g]));
-            SF_HIP(hipEventRecord(e_B[g], bs[g]));
+            SF_TRY(sf_exec_event(ex, &e_last[g]));
+            SF_HIP(hipEventRecord(e_last[g], bs[g]));
+            readers[k & 3].push_back(e_last[g]);
+            readers[(k + 1) & 3].push_back(e_last[g]);
+        }
+    }
+    // narrow tail (also: a trailing single panel, pairs without rows below them)
+    for (; k < nt; ++k) {
+        const int k0 = k * GT;
+        const int pw = (n - k0 < GT) ? n - k0 : GT;
+        if (e_A) {  // the tile parked by the last wide A launch, and the rows of its two slabs
+            SF_HIP(hipStreamWaitEvent(c, e_A, 0));
+            for (int g = 0; g < 2; ++g) SF_HIP(hipStreamWaitEvent(bs[g], e_A, 0));
+            e_A = nullptr;
+        }
+        SF_TRY(wait_readers(k & 3));
+        SF_TRY(diag(k));
+        if (k + 1 >= nt) break;
+        hipEvent_t e_d;
+        SF_TRY(sf_exec_event(ex, &e_d));
+        SF_HIP(hipEventRecord(e_d, c));
+        // top(k): the slab of the next diagonal tile, on the chain; its rows were finished by the group of its parity
+        if (e_last[(k + 1) & 1]) SF_HIP(hipStreamWaitEvent(c, e_last[(k + 1) & 1], 0));
+        SF_TRY(narrow(k0, pw, (k + 1) * GT, 1, 1, Wslot(k), true, c, 0));
+        for (int g = 0; g < 2; ++g) {
+            int first = k + 2;
+            if ((first & 1) != g) ++first;
+            if (first >= nt) continue;
+            const int cnt = (nt - 1 - first) / 2 + 1;
+            SF_HIP(hipStreamWaitEvent(bs[g], e_d, 0));
+            SF_TRY(narrow(k0, pw, first * GT, cnt, 2, Wslot(k), false, bs[g], 1 + g));
+            SF_TRY(sf_exec_event(ex, &e_last[g]));
+            SF_HIP(hipEventRecord(e_last[g], bs[g]));
+            readers[k & 3].push_back(e_last[g]);
         }
     }
     hipEvent_t e_join;
@@ -2620,10 +2644,7 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
     SF_HIP(hipEventRecord(e_join, c));
     SF_HIP(hipStreamWaitEvent(s, e_join, 0));
     if (e_A) SF_HIP(hipStreamWaitEvent(s, e_A, 0));
-    for (int g = 0; g < 2; ++g) {
-        if (e_B[g] && bs[g] != s) SF_HIP(hipStreamWaitEvent(s, e_B[g], 0));
-        if (e_Bprev[g] && bs[g] != s) SF_HIP(hipStreamWaitEvent(s, e_Bprev[g], 0));
-    }
+    if (e_last[1]) SF_HIP(hipStreamWaitEvent(s, e_last[1], 0));
     return SF_OK;
 }
 
@@ -2766,10 +2787,13 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     // but one workgroup per CU has nothing to overlap its epilogue and barriers with.  Measured (bench.py, same box):
     // cfg 2 (N = 4096, B = 128) 0.5-1 % faster, cfg 3 (1600 units of N = 3008) equal, cfg 5 (N = 16384, B = 32) 2.4 %
     // slower, B <= 64 slower -> taken only for full batches of mid-size matrices.
-    const bool wide_auto = batch >= 96 && batch <= 512 && n >= 2048 && n <= 8192;
+    const bool wide_auto = batch >= 96 && n >= 2048;
     const bool v3 = sel >= 0 ? sel == 2 : (force ? force[0] == '2' : wide_auto);
     if (!ex) ex = sf_exec_thread_local();
-    if (v3) return sf_launch_potrf_v3(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
+    static const int tail_env = SF_TUNE_INT("SF_WIDE_TAIL_ROUNDS", -1);  // measured at cfg 2: -1 (wide to the end) 49.3 ms, 2: 50.0, 5: 50.4, 8: 51.0, 12: 51.8 (narrow: 51.5)
+    const bool v3h = sel == 3;  // (test aid) wide pairs for the first half of the panels, narrow steps after
+    if (v3 || v3h)
+        return sf_launch_potrf_v3(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex, v3h ? -2 : (sel == 2 ? -1 : tail_env));
     return v1 ? sf_launch_potrf_v1(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex)
               : sf_launch_potrf_v2(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
 }
