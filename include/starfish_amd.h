@@ -317,6 +317,14 @@ int sf_band_logdet_gram_batch(const double* d_band, int n, int halfwidth, int ld
 int sf_profile_enable(int on);
 int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches, long* calls);
 
+/* Emulator training likelihood (Starfish/emulator/emulator.py:602-619): the matrix
+ * v11 = iPhiPhi / lambda_xi + blockdiag_c(variance_c RBF_c(grid, grid)) (emulator.py:126-128, kernels.py:5-49) built on
+ * the device into the padded layout of sf_potrf_batch: d_A[npad][lda], identity block from n = m M to npad.
+ * d_grid[M*P], d_hyper = {lambda_xi, variances[m], lengthscales[m*P]}, d_iphiphi[n*n].  Emulator.train calls it once per
+ * objective evaluation, followed by sf_potrf_batch + sf_logdet_sqmah_batch with the right-hand side w_hat. */
+int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, const double* d_hyper, const double* d_iphiphi,
+                          double* d_A, int npad, int lda, void* stream);
+
 /* Tuning / test aid (process-global): the batched Cholesky has three launch sequences -- the fused panel kernel
  * (128-column panels, two workgroups per CU; the default once the batch fills the chip), the unfused one (256-column
  * panels, separate panel-solve and diagonal-update launches; fewer sequential steps, faster for batches below ~28

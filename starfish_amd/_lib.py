@@ -87,6 +87,7 @@ SIGNATURES = {
     ),
     "sf_extinct_ccm89": (C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_double, C.c_double, _VP, _VP]),
     "sf_extinct": (C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_double, C.c_double, C.c_int, _VP, _VP]),
+    "sf_emulator_v11_build": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, C.c_int, C.c_int, _VP]),
     "sf_potrf_batch": (
         C.c_int,
         [_VP, C.c_int, C.c_int, C.c_int64, C.c_int, _VP, _VP, C.c_size_t, _VP],

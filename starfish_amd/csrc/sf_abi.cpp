@@ -1613,6 +1613,11 @@ extern "C" int sf_logdet_sqmah_batch(const double* d_L, int n, int lda, int64_t 
                                   (hipStream_t)stream);
 }
 
+extern "C" int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, const double* d_hyper, const double* d_iphiphi,
+                                     double* d_A, int npad, int lda, void* stream) {
+    return sf_launch_v11_build(d_grid, M, P, m, d_hyper, d_iphiphi, d_A, npad, lda, (hipStream_t)stream);
+}
+
 // Tuning / test aid: pin the launch sequence of the batched Cholesky (process-global).
 extern "C" int sf_debug_cholesky_sequence(int mode) { return sf_set_cholesky_sequence(mode); }
 

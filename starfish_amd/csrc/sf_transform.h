@@ -107,3 +107,5 @@ int sf_launch_emulator(const sf_emu_args& a, int B, hipStream_t s);
 int sf_launch_emu_joint(const sf_emu_args& a, int B, const double* mu_pts, double* mu, double* cov, hipStream_t s);
 int sf_launch_finish(int B, const double* logdet, const double* sqmah, const int* info, const int* info2,
                      double* lnl, int* info_out, hipStream_t s);
+int sf_launch_v11_build(const double* grid, int M, int P, int m, const double* hyper, const double* iphiphi, double* A, int npad,
+                        int lda, hipStream_t s);

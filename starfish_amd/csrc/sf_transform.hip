@@ -1210,3 +1210,49 @@ int sf_launch_finish(int B, const double* logdet, const double* sqmah, const int
     SF_LAUNCH_CHECK();
     return SF_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// v11 = iPhiPhi / lambda_xi + blockdiag_c( variance_c exp(-1/2 |(x_i - x_j) / lengthscale_c|^2) )  of the emulator's
+// training likelihood (Starfish/emulator/emulator.py:126-128,569-571; kernels.py:5-49), built ON the device into the
+// padded layout the batched Cholesky takes (identity block from n = m M to npad): Emulator.train evaluates it once per
+// objective call, and the host build + upload of the 1320 x 1320 matrix of the worked example cost 5x the
+// factorisation.  hyper = [lambda_xi, variances[m], lengthscales[m][P]] (device).  Operation order of the reference:
+// (x / l) differences squared and summed over the parameters in order, -0.5 * d2, exp, times the variance, added to
+// iPhiPhi / lambda_xi.
+__global__ __launch_bounds__(256) void k_v11_build(const double* __restrict__ grid, int M, int P, int m,
+                                                   const double* __restrict__ hyper, const double* __restrict__ iphiphi,
+                                                   double* __restrict__ A, int npad, int lda) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= npad) return;
+    const int n = m * M;
+    double v;
+    if (i < n && j < n) {
+        v = iphiphi[(int64_t)i * n + j] / hyper[0];
+        const int ci = i / M, cj = j / M;
+        if (ci == cj) {
+            const double* gi = grid + (int64_t)(i - ci * M) * P;
+            const double* gj = grid + (int64_t)(j - cj * M) * P;
+            const double* ls = hyper + 1 + m + ci * P;
+            double d2 = 0.0;
+            for (int p = 0; p < P; ++p) {
+                const double d = gi[p] / ls[p] - gj[p] / ls[p];
+                d2 = d2 + d * d;
+            }
+            v = v + hyper[1 + ci] * exp(-0.5 * d2);
+        }
+    } else {
+        v = (i == j) ? 1.0 : 0.0;
+    }
+    A[(int64_t)i * lda + j] = v;
+}
+int sf_launch_v11_build(const double* grid, int M, int P, int m, const double* hyper, const double* iphiphi, double* A, int npad,
+                        int lda, hipStream_t s) {
+    if (!grid || !hyper || !iphiphi || !A || M <= 0 || P <= 0 || m <= 0 || npad < m * M || lda < npad) {
+        sf_set_error("v11_build: bad arguments");
+        return SF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_v11_build, dim3((npad + 255) / 256, npad), dim3(256), 0, s, grid, M, P, m, hyper, iphiphi, A, npad, lda);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}

@@ -71,16 +71,35 @@ class Emulator:
         self.w_hat = np.asarray(w_hat, dtype=np.float64)
         self._trained = False
         self._device = None
+        self._v11_assigned = False
+        self._train_dev = None
         self._refresh_v11()
 
     # ----------------------------------------------------------------- hyper-parameters
     def _refresh_v11(self):
-        # emulator.py:126-128 / 569-571
-        self.v11 = self.iPhiPhi / self.lambda_xi + batch_kernel(
-            self.grid_points, self.grid_points, self.variances, self.lengthscales
-        )
+        """The hyper-parameters changed: v11 (emulator.py:126-128 / 569-571) is rebuilt on the HOST only when somebody
+        reads it (queries, model contexts) -- the training objective builds and factors it on the device
+        (:meth:`log_likelihood`), so a Nelder-Mead step does not pay the 17 ms numpy build of the 1320 x 1320 matrix
+        of the worked example."""
+        self._v11 = None
+        self._v11_assigned = False
         self._device = None  # the device-side factor of v11 is rebuilt lazily
         self._factor = None
+
+    @property
+    def v11(self):
+        if self._v11 is None:
+            self._v11 = self.iPhiPhi / self.lambda_xi + batch_kernel(
+                self.grid_points, self.grid_points, self.variances, self.lengthscales
+            )
+        return self._v11
+
+    @v11.setter
+    def v11(self, value):
+        self._v11 = None if value is None else np.asarray(value, dtype=np.float64)
+        self._device = None
+        self._factor = None
+        self._v11_assigned = value is not None  # an explicitly assigned matrix is what log_likelihood factors
 
     def v11_factor(self):
         """(Linv, alpha) of the current v11, computed once per hyper-parameter set and handed to every order
@@ -331,38 +350,52 @@ class Emulator:
         raise NotImplementedError("Emulator.from_grid (PCA of a spectral library) is offline set-up, out of scope")
 
     def log_likelihood(self):
-        """-(logdet v11 + w_hat^T v11^-1 w_hat) / 2  (Starfish/emulator/emulator.py:602-619), with the
-        Cholesky factorisation and the solve done by the same batched HIP kernels as the spectrum
-        likelihood (``sf_potrf_batch`` / ``sf_logdet_sqmah_batch``)."""
-        import ctypes as C
-
+        """-(logdet v11 + w_hat^T v11^-1 w_hat) / 2  (Starfish/emulator/emulator.py:602-619), entirely on the device:
+        v11 is built from the hyper-parameters by ``sf_emulator_v11_build`` (grid, iPhiPhi and w_hat stay resident), then
+        factored and solved by the same batched HIP kernels as the spectrum likelihood (``sf_potrf_batch`` /
+        ``sf_logdet_sqmah_batch``).  One small upload (the hyper-parameters) and one small download
+        per call.  A matrix assigned to ``self.v11`` by hand is uploaded and factored as it is."""
         from .. import _lib
 
         lib = _lib.require_gpu()
         torch = D._torch()
         dev = D.device_of()
-        n = self.v11.shape[0]
+        M, P = self.grid_points.shape
+        m = self.ncomps
+        n = m * M
         npad = -(-n // 64) * 64
         lda = npad + 16
-        A = np.zeros((1, npad, lda))
-        A[0, :n, :n] = self.v11
-        idx = np.arange(n, npad)
-        A[0, idx, idx] = 1.0  # identity padding: log 1 = 0, zero right-hand side
-        R = np.zeros((1, npad))
-        R[0, :n] = self.w_hat
-        dA, dR = D.to_dev(A, dev), D.to_dev(R, dev)
-        info = D.empty((1,), dev, torch.int32)
-        ld, sq = D.empty((1,), dev), D.empty((1,), dev)
-        ws = D.workspace(lib.sf_potrf_workspace_bytes(npad, 1), dev)
+        td = self._train_dev
+        if td is None or td["dev"] != dev or td["w_hat"] is not self.w_hat:
+            R = np.zeros(npad)
+            R[:n] = self.w_hat
+            td = self._train_dev = dict(
+                dev=dev, w_hat=self.w_hat, grid=D.to_dev(self.grid_points, dev), iphiphi=D.to_dev(self.iPhiPhi, dev),
+                R=D.to_dev(R, dev), A=D.empty((npad, lda), dev), out=D.empty((2,), dev), info=D.empty((1,), dev, torch.int32),
+                ws=D.workspace(lib.sf_potrf_workspace_bytes(npad, 1), dev),
+            )
         s = D.stream_ptr(dev)
-        _lib.check(lib.sf_potrf_batch(D.ptr(dA), npad, lda, npad * lda, 1, D.ptr(info), D.ptr(ws), ws.numel(), s),
+        A = td["A"]
+        if self._v11_assigned:
+            host = np.zeros((npad, lda))
+            host[:n, :n] = self._v11
+            idx = np.arange(n, npad)
+            host[idx, idx] = 1.0  # identity padding: log 1 = 0, zero right-hand side
+            A.copy_(torch.from_numpy(host))
+        else:
+            hyper = D.to_dev(np.concatenate([[self.lambda_xi], self.variances, np.asarray(self.lengthscales).ravel()]), dev)
+            _lib.check(lib.sf_emulator_v11_build(D.ptr(td["grid"]), M, P, m, D.ptr(hyper), D.ptr(td["iphiphi"]), D.ptr(A),
+                                                 npad, lda, s), "sf_emulator_v11_build")
+        ws = td["ws"]
+        _lib.check(lib.sf_potrf_batch(D.ptr(A), npad, lda, npad * lda, 1, D.ptr(td["info"]), D.ptr(ws), ws.numel(), s),
                    "sf_potrf_batch")
-        _lib.check(lib.sf_logdet_sqmah_batch(D.ptr(dA), npad, lda, npad * lda, 1, D.ptr(dR), npad, D.ptr(ws),
-                                             ws.numel(), D.ptr(ld), D.ptr(sq), s), "sf_logdet_sqmah_batch")
-        code = int(info.cpu()[0])
+        _lib.check(lib.sf_logdet_sqmah_batch(D.ptr(A), npad, lda, npad * lda, 1, D.ptr(td["R"]), npad, D.ptr(ws),
+                                             ws.numel(), D.ptr(td["out"][0:1]), D.ptr(td["out"][1:2]), s), "sf_logdet_sqmah_batch")
+        code = int(td["info"].cpu()[0])
         if code != 0:
             raise np.linalg.LinAlgError(f"{code}-th leading minor of the array is not positive definite")
-        return -(float(ld.cpu()[0]) + float(sq.cpu()[0])) / 2
+        ld, sq = td["out"].cpu().tolist()
+        return -(ld + sq) / 2
 
     def train(self, **opt_kwargs):
         """Nelder-Mead over the hyper-parameter vector (Starfish/emulator/emulator.py:484-524); every

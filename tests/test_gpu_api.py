@@ -281,3 +281,44 @@ def test_emulator_training_likelihood_worked_example_size_vs_reference():
     got = emu.log_likelihood()
     assert abs(got - want) <= 1e-9 * abs(want), (got, want)
     assert got == emu.log_likelihood()  # deterministic
+
+
+def test_device_built_v11_matches_the_host_matrix():
+    """sf_emulator_v11_build (the training objective's matrix, built from the hyper-parameters on the device) against the
+    host numpy build the queries use (emulator.py:126-128; kernels.py:5-49), identity padding included; a matrix assigned
+    by hand is factored as it is; changing a hyper-parameter drops it."""
+    import torch
+
+    from starfish_amd import _device as D
+    from starfish_amd import _lib
+
+    o = synth.make_order(N=256, m=4, seed=3)
+    rng = np.random.default_rng(11)
+    emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"], o["w_hat"],
+                   o["flux_mean"], o["flux_std"], o["factors"], variances=np.exp(rng.uniform(2, 8, 4)),
+                   lengthscales=np.exp(rng.uniform(-0.5, 0.5, (4, 3))) * np.array([300.0, 1.5, 1.5]), lambda_xi=1.7)
+    lib = _lib.require_gpu()
+    dev = D.device_of()
+    M, P = emu.grid_points.shape
+    n = 4 * M
+    npad = -(-n // 64) * 64
+    lda = npad + 16
+    A = torch.full((npad, lda), np.nan, dtype=torch.float64, device=dev)
+    hyper = D.to_dev(np.concatenate([[emu.lambda_xi], emu.variances, emu.lengthscales.ravel()]), dev)
+    d_grid, d_iphiphi = D.to_dev(emu.grid_points, dev), D.to_dev(emu.iPhiPhi, dev)  # (kept alive across the launch)
+    _lib.check(lib.sf_emulator_v11_build(D.ptr(d_grid), M, P, 4, D.ptr(hyper), D.ptr(d_iphiphi), D.ptr(A), npad, lda,
+                                         D.stream_ptr(dev)))
+    got = A.cpu().numpy()
+    np.testing.assert_allclose(got[:n, :n], emu.v11, rtol=1e-13, atol=1e-300)
+    np.testing.assert_array_equal(got[n:, :npad], np.eye(npad)[n:])
+    assert not got[:n, n:npad].any() and np.isnan(got[:, npad:]).all()  # the 16 spare columns of a row are never touched
+    base = emu.log_likelihood()
+    emu.v11 = emu.v11 + 0.5 * np.eye(n)  # assigned by hand: factored as given
+    shifted = emu.log_likelihood()
+    from scipy.linalg import cho_factor, cho_solve
+
+    f = cho_factor(emu.v11)
+    want = -(2 * np.sum(np.log(f[0].diagonal())) + emu.w_hat @ cho_solve(f, emu.w_hat)) / 2
+    assert abs(shifted - want) <= 1e-10 * abs(want) and shifted != base
+    emu.set_param_vector(emu.get_param_vector())  # hyper-parameters rule again
+    assert abs(emu.log_likelihood() - base) <= 1e-12 * abs(base)
