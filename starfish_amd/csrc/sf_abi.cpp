@@ -112,7 +112,11 @@ int sf_exec_prepare(sf_exec* ex) {
         int prio_lo = 0, prio_hi = 0;
         SF_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         SF_HIP(hipStreamCreateWithPriority(&ex->side, hipStreamNonBlocking, prio_hi));
-        SF_HIP(hipStreamCreateWithFlags(&ex->aux, hipStreamNonBlocking));
+        // (high priority too: in a multi-order call the next chunk's transform chains and fills -- dozens of small launches
+        // per order -- run on it beside the factorisation, whose workgroups take a CU's whole register file; at normal
+        // priority they only got CUs when a big launch drained: 16 of the 21 orders of cfg 3's second chunk were filled
+        // AFTER the first chunk's factorisation, 16.7 ms of a 276 ms step with nothing else running)
+        SF_HIP(hipStreamCreateWithPriority(&ex->aux, hipStreamNonBlocking, prio_hi));
         SF_HIP(hipStreamCreateWithPriority(&ex->xa, hipStreamNonBlocking, prio_hi));
         for (int g = 0; g < SF_EXEC_GROUPS - 1; ++g) SF_HIP(hipStreamCreateWithFlags(&ex->grp[g], hipStreamNonBlocking));
         SF_HIP(hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming));
@@ -657,16 +661,19 @@ struct Work {
     unsigned char* tilemap;
     size_t bytes, ltbuf_stride;
     Layout L;
+    int trans_bt = 0;      // walkers one set of transient buffers is sized for
+    size_t fft_set = 0;    // double2 per set
 };
 // B units of per-unit buffers; the transient buffers of the transform chain (used by one launch sequence at a
 // time, stream ordered) are sized for Bt walkers
+// (trans_sets > 1: that many independent sets of the transient buffers, for transform chains running side by side)
 static Work carve(const Layout& L, const sf_model_desc* mdl, int B, int Bt, void* p, size_t cap, bool need_C,
-                  int potrf_units = 0, int potrf_slots = 1) {
+                  int potrf_units = 0, int potrf_slots = 1, int trans_sets = 1) {
     Carve k(p, cap);
     Work w;
     w.L = L;
     if (potrf_units <= 0) potrf_units = B;
-    const size_t b = (size_t)B, bt = (size_t)Bt;
+    const size_t b = (size_t)B, bt = (size_t)Bt * (size_t)trans_sets;
     w.mu = k.take<double>(b * L.m);
     w.Lw = k.take<double>(b * L.m * L.m);
     w.zs = k.take<double>(b * L.m * L.M * L.m);
@@ -680,7 +687,9 @@ static Work carve(const Layout& L, const sf_model_desc* mdl, int B, int Bt, void
     w.ybro = mdl->has_vsini ? k.take<double>(bt * L.nf * L.rows) : nullptr;  // broadened rows before the fit
     w.mult = mdl->has_vsini ? k.take<double>(bt * (L.nf / 2 + 1)) : nullptr;  // broadening kernel per walker
     const size_t fb = mdl->has_vsini ? sf_fft_half_scratch_bytes(Bt * L.rows, L.nf) : 0;
-    w.fft = fb ? k.take<double2>(fb / sizeof(double2)) : nullptr;
+    w.fft = fb ? k.take<double2>(fb / sizeof(double2) * (size_t)trans_sets) : nullptr;
+    w.trans_bt = Bt;
+    w.fft_set = fb / sizeof(double2);
     w.Xraw = k.take<double>(b * L.m * L.npad);
     w.fraw = k.take<double>(b * L.npad);
     w.resid = k.take<double>(b * L.npad);
@@ -719,6 +728,17 @@ static Work slice(const Work& w, int u0) {
     if (s.tilemap) s.tilemap += u * tilemap_bytes(L);
     if (s.gtab) s.gtab += u * (size_t)L.npad;
     if (s.C) s.C += u * (size_t)L.npad * L.lda;
+    return s;
+}
+// set `set` of the transient buffers (multi-order calls run several orders' transform chains side by side)
+static Work with_trans_set(const Work& w, int set) {
+    Work s = w;
+    const Layout& L = w.L;
+    const size_t o = (size_t)set * (size_t)w.trans_bt;
+    if (s.coef) s.coef += o * L.nf * L.rows;
+    if (s.ybro) s.ybro += o * L.nf * L.rows;
+    if (s.mult) s.mult += o * (L.nf / 2 + 1);
+    if (s.fft) s.fft += (size_t)set * w.fft_set;
     return s;
 }
 extern "C" size_t sf_workspace_bytes(const sf_ctx* c, const sf_model_desc* mdl, int B) {
@@ -1091,6 +1111,9 @@ static int multi_layout(const sf_segment* segs, int nseg, const sf_model_desc* m
 // Chunks of a multi-order call (whole segments): a SMALL first chunk (at least 256 units: enough matrices to keep a
 // factorisation's launches full) and the rest as the second -- only the first chunk's fills are exposed, the others
 // run behind the first factorisation.  (Equal chunks: 1, 2, 3, 4 of them gave 283.1, 282.1, 282.7, 283.9 ms at cfg 3.)
+// Orders whose transform chains + fills run side by side (own stream and own set of transient buffers each): a chain is
+// ~14 small dependent launches, latency-bound -- alone it takes ~1 ms per order with the chip idle around it.
+#define SF_MULTI_LANES 4  // (6 and 8 lanes measured: no further gain)
 static int multi_first_units(int U) {
     static const int first = std::max(1, SF_TUNE_INT("SF_MULTI_FIRST", 256));  // tuning aid
     return std::min(U, first);
@@ -1100,7 +1123,7 @@ extern "C" size_t sf_multi_workspace_bytes(const sf_segment* segs, int nseg, con
     Layout L;
     int U = 0, bmax = 0;
     if (multi_layout(segs, nseg, mdl, &L, &U, &bmax)) return 0;
-    return carve(L, mdl, U, bmax, nullptr, 0, true, multi_chunk_cap(U, bmax), 1).bytes;
+    return carve(L, mdl, U, bmax, nullptr, 0, true, multi_chunk_cap(U, bmax), 1, SF_MULTI_LANES).bytes;
 }
 extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf_model_desc* mdl, double* d_lnl,
                                       double* d_logdet, double* d_sqmah, double* d_log_scale, int* d_info,
@@ -1113,7 +1136,7 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
         sf_set_error("sf_loglike_multi_batch: d_lnl and a workspace are required");
         return SF_EINVAL;
     }
-    const size_t need = carve(L, mdl, U, bmax, nullptr, 0, true, multi_chunk_cap(U, bmax), 1).bytes;
+    const size_t need = carve(L, mdl, U, bmax, nullptr, 0, true, multi_chunk_cap(U, bmax), 1, SF_MULTI_LANES).bytes;
     if (work_bytes < need) {
         sf_set_error("workspace too small: have %zu, need %zu", work_bytes, need);
         return SF_ENOMEM;
@@ -1121,7 +1144,7 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
     sf_ctx* c0 = segs[0].ctx;
     if (use_device(c0)) return SF_EHIP;
     hipStream_t s = (hipStream_t)stream;
-    Work W = carve(L, mdl, U, bmax, d_work, work_bytes, true, multi_chunk_cap(U, bmax), 1);
+    Work W = carve(L, mdl, U, bmax, d_work, work_bytes, true, multi_chunk_cap(U, bmax), 1, SF_MULTI_LANES);
     prof_count_call();
     const int64_t stride = (int64_t)L.npad * L.lda;
     const int nt128 = (L.npad + 127) / 128;
@@ -1132,22 +1155,29 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
     rc = sf_exec_prepare(ex);
     if (rc) return rc;
     static const bool no_pipe = SF_TUNE_FLAG("SF_MULTI_NO_PIPELINE");  // tuning aid
-    hipStream_t sp = no_pipe ? s : ex->aux;
+    static const int lanes_env = SF_TUNE_INT("SF_MULTI_LANES_USED", SF_MULTI_LANES);
+    const int nlanes = no_pipe ? 1 : std::max(1, std::min(lanes_env, SF_MULTI_LANES));
+    // (the factorisation has its own executor, exec_potrf: all four streams of `ex` are free for the chains)
+    hipStream_t lane_stream[SF_MULTI_LANES] = {no_pipe ? s : ex->aux, ex->side, ex->xa, ex->grp[0]};
     const int first_units = multi_first_units(U);
-    if (sp != s) {
+    if (!no_pipe) {
         SF_HIP(hipEventRecord(ex->fork, s));
-        SF_HIP(hipStreamWaitEvent(sp, ex->fork, 0));
+        for (int l = 0; l < nlanes; ++l) SF_HIP(hipStreamWaitEvent(lane_stream[l], ex->fork, 0));
     }
     struct Chunk {
         int u0, units;
-        hipEvent_t filled;
+        hipEvent_t filled[SF_MULTI_LANES];
     };
     std::vector<Chunk> chunks;
+    bool lane_used[SF_MULTI_LANES] = {};
     int u0 = 0, cu0 = 0;
     for (int i = 0; i < nseg; ++i) {
         sf_ctx* c = segs[i].ctx;
         const int B = segs[i].B;
-        Work w = slice(W, u0);
+        const int lane = i % nlanes;
+        hipStream_t sp = lane_stream[lane];
+        lane_used[lane] = true;
+        Work w = with_trans_set(slice(W, u0), lane);
         {
             ProfScope ps(sp, PS_TRANSFORM);
             rc = run_transforms(c, mdl, B, segs[i].d_params, w, nullptr, nullptr, nullptr,
@@ -1170,11 +1200,13 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
         }
         u0 += B;
         if ((chunks.empty() && u0 - cu0 >= first_units) || i == nseg - 1) {
-            Chunk ch{cu0, u0 - cu0, nullptr};
-            if (sp != s) {
-                rc = sf_exec_event(ex, &ch.filled);
+            Chunk ch{cu0, u0 - cu0, {}};
+            for (int l = 0; l < nlanes; ++l) {
+                if (!lane_used[l] || lane_stream[l] == s) continue;
+                rc = sf_exec_event(ex, &ch.filled[l]);
                 if (rc) return rc;
-                SF_HIP(hipEventRecord(ch.filled, sp));
+                SF_HIP(hipEventRecord(ch.filled[l], lane_stream[l]));
+                lane_used[l] = false;
             }
             chunks.push_back(ch);
             cu0 = u0;
@@ -1184,7 +1216,8 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
     // Two factorisations in flight on two streams, to hide one's under-filled last panels behind the other, were
     // measured slower: 306 vs 291 ms at cfg 3.)
     for (const Chunk& ch : chunks) {
-        if (ch.filled) SF_HIP(hipStreamWaitEvent(s, ch.filled, 0));
+        for (int l = 0; l < SF_MULTI_LANES; ++l)
+            if (ch.filled[l]) SF_HIP(hipStreamWaitEvent(s, ch.filled[l], 0));
         Work w = slice(W, ch.u0);
         {
             ProfScope ps(s, PS_POTRF);

@@ -20,3 +20,14 @@ for solver in ("auto", "dense"):
     for _ in range(n): ll = m.log_likelihood_batch(P)
     dt = (time.perf_counter() - t0) / n
     print(f"solver={solver}: SpectrumModel.log_likelihood_batch(128 walkers): {dt*1e3:.2f} ms per call -> {128/dt:.0f} evals/s (python API, host-side packing and copies included)")
+
+# the multi-order model (cfg-3 shape) through the same API, dense solver: host packing of 25 orders, plan set-up, copies
+if "--echelle" in sys.argv:
+    orders = synth.make_echelle(25, 3000)
+    em = synth.build_echelle(orders)
+    Ps = synth.shared_ball(orders[0], B=64, seed=1)
+    em.log_likelihood_batch(Ps)
+    t0 = time.perf_counter()
+    for _ in range(3): tot = em.log_likelihood_batch(Ps)
+    dt = (time.perf_counter() - t0) / 3
+    print(f"EchelleModel.log_likelihood_batch(25 orders x 3000 px x 64 walkers), dense: {dt*1e3:.1f} ms per call -> {1600/dt:.0f} order-evals/s")
