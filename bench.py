@@ -567,7 +567,7 @@ def main():
         plist0, order0 = w.plist, w.order0
         w.release()
         w2 = Workload(cfg, rank, world, other_mode, args.grid)
-        t2 = timed_leg(w2, args.steps, args.warmup, args.profile_steps, comm)
+        t2 = timed_leg(w2, args.steps, max(2, args.warmup), args.profile_steps, comm)  # (a new batch size: >= 2 untimed steps)
         other = short_summary(w2, t2)
         other["scaling"] = other_mode
         other["n_gpus"] = world
