@@ -659,6 +659,8 @@ struct Work {
     double2* fft;
     int *info_e, *info_c;
     unsigned char* tilemap;
+    unsigned short* tilelist;  // compact list of the materialised tiles (see sf_fill_args)
+    int* tilecount;
     size_t bytes, ltbuf_stride;
     Layout L;
     int trans_bt = 0;      // walkers one set of transient buffers is sized for
@@ -698,6 +700,8 @@ static Work carve(const Layout& L, const sf_model_desc* mdl, int B, int Bt, void
     w.ltbuf_stride = sf_align_up(sf_potrf_work_doubles(L.npad, potrf_units), 32);
     w.ltbuf = need_C ? k.take<double>(w.ltbuf_stride * potrf_slots) : nullptr;  // Cholesky scratch (per concurrent call)
     w.tilemap = need_C ? k.take<unsigned char>(b * tilemap_bytes(L)) : nullptr;
+    w.tilelist = need_C ? k.take<unsigned short>(b * tilemap_bytes(L)) : nullptr;  // (capacity: every tile)
+    w.tilecount = need_C ? k.take<int>(b) : nullptr;
     w.gtab = need_C ? k.take<double>(b * (size_t)L.npad) : nullptr;
     w.C = need_C ? k.take<double>(b * (size_t)L.npad * L.lda) : nullptr;
     w.bytes = sf_align_up(k.off, 256);
@@ -726,6 +730,8 @@ static Work slice(const Work& w, int u0) {
     s.Y += u * L.mpad * L.npad;
     s.ztrsv += u * L.npad;
     if (s.tilemap) s.tilemap += u * tilemap_bytes(L);
+    if (s.tilelist) s.tilelist += u * tilemap_bytes(L);
+    if (s.tilecount) s.tilecount += u;
     if (s.gtab) s.gtab += u * (size_t)L.npad;
     if (s.C) s.C += u * (size_t)L.npad * L.lda;
     return s;
@@ -897,6 +903,9 @@ static sf_fill_args fill_args(sf_ctx* c, const sf_model_desc* mdl, const double*
     f.loguniform = c->loguniform;
     f.tilemap = nullptr;
     f.nt128 = 0;
+    f.tilelist = nullptr;
+    f.tilecount = nullptr;
+    f.list_cap = 0;
     f.gtab = nullptr;
     return f;
 }
@@ -1039,6 +1048,9 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
         f.add_jitter = 1;
         f.gtab = w.gtab;        // per-diagonal table of the global kernel (used on log-uniform grids only)
         f.tilemap = w.tilemap;  // only tiles that carry more than the rank-m term are materialised
+        f.tilelist = w.tilelist;
+        f.tilecount = w.tilecount;
+        f.list_cap = (int)tilemap_bytes(layout_of(c));
         f.nt128 = (c->npad + 127) / 128;
         rc = sf_launch_fill(f, B, s);
         if (rc) return rc;
@@ -1194,6 +1206,9 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
             f.add_jitter = 1;
             f.gtab = w.gtab;
             f.tilemap = w.tilemap;
+            f.tilelist = w.tilelist;
+            f.tilecount = w.tilecount;
+            f.list_cap = (int)tilemap_bytes(L);
             f.nt128 = nt128;
             rc = sf_launch_fill(f, B, sp);
             if (rc) return rc;

@@ -145,6 +145,12 @@ struct sf_fill_args {
     int loguniform;        // wave_i = wave_0 e^(i delta) to rounding -> K_global depends on i-j only
     unsigned char* tilemap; // optional [B][nt128*nt128]: 1 = the 128x128 tile is materialised in C
     int nt128;
+    // optional compact work list of the materialised tiles (likelihood path): k_tile_map appends (tm << 8 | tn) per flagged
+    // 128 x 128 tile, the fill then launches a few workgroups per walker that walk the list instead of one (mostly empty)
+    // workgroup per 64 x 64 tile of the whole matrix
+    unsigned short* tilelist;  // [B][list_cap]
+    int* tilecount;            // [B]
+    int list_cap;
     double* gtab;          // optional [B][n] scratch: K_global per diagonal (log-uniform grids, likelihood path)
 };
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);

@@ -84,6 +84,10 @@ __global__ __launch_bounds__(256) void k_tile_map(sf_fill_args a) {
         }
     }
     a.tilemap[(int64_t)b * nt * nt + e] = flag;
+    if (flag && a.tilelist) {
+        const int idx = atomicAdd(&a.tilecount[b], 1);  // (the order of the list does not matter: tiles are independent)
+        if (idx < a.list_cap) a.tilelist[(int64_t)b * a.list_cap + idx] = (unsigned short)((tm << 8) | tn);
+    }
 }
 
 // Every stored tile in ONE pass: rank-m term on MFMA + sigma^2 on the diagonal + identity padding, and
@@ -92,12 +96,7 @@ __global__ __launch_bounds__(256) void k_tile_map(sf_fill_args a) {
 // (spectrum_model.py:338, 348, 353-363, 399).  Write-only: the pass is HBM-write bound (a separate band
 // pass used to read-modify-write the same tiles: 1.15 -> 0.5 ms at cfg 2).
 template <bool BAND>
-__global__ __launch_bounds__(256, BAND ? 2 : 4) void k_fill_tiles(sf_fill_args a, int nt) {
-    const int id = sf_xcd_remap_f(blockIdx.x, gridDim.x);
-    const int tiles = nt * nt;
-    const int b = id / tiles;
-    const int t = id - b * tiles;
-    const int tm = t / nt, tn = t - tm * nt;
+__device__ __forceinline__ void sf_fill_tile(const sf_fill_args& a, int b, int tm, int tn) {
     if (a.lower_only && tn > tm) return;
     if (a.tilemap && !a.tilemap[(int64_t)b * a.nt128 * a.nt128 + (tm >> 1) * a.nt128 + (tn >> 1)]) return;
 
@@ -247,6 +246,28 @@ __global__ __launch_bounds__(256, BAND ? 2 : 4) void k_fill_tiles(sf_fill_args a
     }
 }
 
+template <bool BAND>
+__global__ __launch_bounds__(256, BAND ? 2 : 4) void k_fill_tiles(sf_fill_args a, int nt) {
+    const int id = sf_xcd_remap_f(blockIdx.x, gridDim.x);
+    const int tiles = nt * nt;
+    const int b = id / tiles;
+    const int t = id - b * tiles;
+    sf_fill_tile<BAND>(a, b, t / nt, t - (t / nt) * nt);
+}
+// The likelihood path: G workgroups per walker walk the walker's list of materialised 128 x 128 tiles (four 64 x 64 tiles
+// each).  The one-workgroup-per-tile grid above is 524 288 workgroups at cfg 2 of which nine in ten leave at once:
+// dispatch-bound (0.70 ms for 0.9 GB written).
+template <bool BAND>
+__global__ __launch_bounds__(256, BAND ? 2 : 4) void k_fill_tiles_list(sf_fill_args a, int G) {
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cnt = min(a.tilecount[b], a.list_cap) * 4;
+    const unsigned short* __restrict__ list = a.tilelist + (int64_t)b * a.list_cap;
+    for (int li = g; li < cnt; li += G) {
+        const int e = list[li >> 2];
+        sf_fill_tile<BAND>(a, b, 2 * (e >> 8) + ((li >> 1) & 1), 2 * (e & 255) + (li & 1));
+    }
+}
+
 __global__ void k_band_gtab(sf_fill_args a, double* __restrict__ gtab, int ws);
 
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
@@ -261,7 +282,9 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
         sf_set_error("fill grid too large");
         return SF_EINVAL;
     }
+    const bool listed = a.tilemap && a.tilelist && a.tilecount && a.lower_only;
     if (a.tilemap) {
+        if (listed) SF_HIP(hipMemsetAsync(a.tilecount, 0, sizeof(int) * (size_t)B, s));
         hipLaunchKernelGGL(k_tile_map, dim3((a.nt128 * a.nt128 + 255) / 256, B), dim3(256), 0, s, a);
         SF_LAUNCH_CHECK();
     }
@@ -272,7 +295,11 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
         hipLaunchKernelGGL(k_band_gtab, dim3((a.n + 255) / 256, B), dim3(256), 0, s, a, a2.gtab, a.n - 1);
         SF_LAUNCH_CHECK();
     }
-    if (structured) hipLaunchKernelGGL(k_fill_tiles<true>, dim3((unsigned)nblk), dim3(256), 0, s, a2, nt);
+    if (listed) {
+        const int G = 64;
+        if (structured) hipLaunchKernelGGL(k_fill_tiles_list<true>, dim3((unsigned)B * G), dim3(256), 0, s, a2, G);
+        else hipLaunchKernelGGL(k_fill_tiles_list<false>, dim3((unsigned)B * G), dim3(256), 0, s, a2, G);
+    } else if (structured) hipLaunchKernelGGL(k_fill_tiles<true>, dim3((unsigned)nblk), dim3(256), 0, s, a2, nt);
     else hipLaunchKernelGGL(k_fill_tiles<false>, dim3((unsigned)nblk), dim3(256), 0, s, a2, nt);
     SF_LAUNCH_CHECK();
     return SF_OK;
