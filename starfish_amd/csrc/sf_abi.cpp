@@ -117,7 +117,6 @@ int sf_exec_prepare(sf_exec* ex) {
         // priority they only got CUs when a big launch drained: 16 of the 21 orders of cfg 3's second chunk were filled
         // AFTER the first chunk's factorisation, 16.7 ms of a 276 ms step with nothing else running)
         SF_HIP(hipStreamCreateWithPriority(&ex->aux, hipStreamNonBlocking, prio_hi));
-        SF_HIP(hipStreamCreateWithPriority(&ex->xa, hipStreamNonBlocking, prio_hi));
         for (int g = 0; g < SF_EXEC_GROUPS - 1; ++g) SF_HIP(hipStreamCreateWithFlags(&ex->grp[g], hipStreamNonBlocking));
         SF_HIP(hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming));
         SF_HIP(hipEventCreateWithFlags(&ex->join, hipEventDisableTiming));
@@ -155,13 +154,12 @@ void sf_exec_release(sf_exec* ex) {
     if (ex->join) (void)hipEventDestroy(ex->join);
     if (ex->side) (void)hipStreamDestroy(ex->side);
     if (ex->aux) (void)hipStreamDestroy(ex->aux);
-    if (ex->xa) (void)hipStreamDestroy(ex->xa);
     for (int g = 0; g < SF_EXEC_GROUPS - 1; ++g) {
         if (ex->grp[g]) (void)hipStreamDestroy(ex->grp[g]);
         ex->grp[g] = nullptr;
     }
     ex->fork = ex->join = nullptr;
-    ex->side = ex->aux = ex->xa = nullptr;
+    ex->side = ex->aux = nullptr;
     ex->device = -1;
 }
 // context-free entry points (sf_potrf_batch, ...): one sf_exec per calling thread and device
@@ -1125,7 +1123,7 @@ static int multi_layout(const sf_segment* segs, int nseg, const sf_model_desc* m
 // run behind the first factorisation.  (Equal chunks: 1, 2, 3, 4 of them gave 283.1, 282.1, 282.7, 283.9 ms at cfg 3.)
 // Orders whose transform chains + fills run side by side (own stream and own set of transient buffers each): a chain is
 // ~14 small dependent launches, latency-bound -- alone it takes ~1 ms per order with the chip idle around it.
-#define SF_MULTI_LANES 4  // (6 and 8 lanes measured: no further gain)
+#define SF_MULTI_LANES 3  // (4, 6 and 8 lanes measured: no further gain)
 static int multi_first_units(int U) {
     static const int first = std::max(1, SF_TUNE_INT("SF_MULTI_FIRST", 256));  // tuning aid
     return std::min(U, first);
@@ -1170,7 +1168,9 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
     static const int lanes_env = SF_TUNE_INT("SF_MULTI_LANES_USED", SF_MULTI_LANES);
     const int nlanes = no_pipe ? 1 : std::max(1, std::min(lanes_env, SF_MULTI_LANES));
     // (the factorisation has its own executor, exec_potrf: all four streams of `ex` are free for the chains)
-    hipStream_t lane_stream[SF_MULTI_LANES] = {no_pipe ? s : ex->aux, ex->side, ex->xa, ex->grp[0]};
+    // (no stream is created for the lanes: every additional ACTIVE stream costs dispatch latency on all of them --
+    // one more for the wide sequence's A launches made a cfg-2 step 3 % slower)
+    hipStream_t lane_stream[SF_MULTI_LANES] = {no_pipe ? s : ex->aux, ex->side, ex->grp[0]};
     const int first_units = multi_first_units(U);
     if (!no_pipe) {
         SF_HIP(hipEventRecord(ex->fork, s));

@@ -2428,7 +2428,11 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
     double* part = Wt2 + 2 * (size_t)batch * sW + 64;
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
     SF_TRY(sf_exec_prepare(ex));
-    hipStream_t c = ex->side, xa = ex->xa;
+    // A(p) sits between chain(p) and chain(p+1) anyway: it shares the chain's stream.  A stream of its own made a cfg-2
+    // step 3 % slower (48.4 -> 50.0 ms: every additional ACTIVE stream costs dispatch latency on all of them -- the
+    // transform chain ahead of the factorisation went from 0.40 to 0.70 ms); at cfg 3, where an A launch is ten rounds of
+    // workgroups, a separate stream measured the same (265.1 / 267.0 vs 266.8 / 265.8 ms).
+    hipStream_t c = ex->side, xa = ex->side;
     hipEvent_t e_fork;
     SF_TRY(sf_exec_event(ex, &e_fork));
     SF_HIP(hipEventRecord(e_fork, s));
@@ -2597,12 +2601,13 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         readers[k & 3].push_back(e_A);
         readers[(k + 1) & 3].push_back(e_A);
         // B(p): slabs k+4 .., slab k+4+g, k+6+g, ... in group g
-        for (int g = 0; g < 2; ++g) {
+        static const int ngrp = SF_TUNE_INT("SF_WIDE_GROUPS", 2);  // tuning aid: 1 = one launch per pair on the caller's stream
+        for (int g = 0; g < ngrp; ++g) {
             const int first = k + 4 + g;
             if (first >= nt) continue;
-            const int cnt = (nt - 1 - first) / 2 + 1;
+            const int cnt = (nt - 1 - first) / ngrp + 1;
             SF_HIP(hipStreamWaitEvent(bs[g], e_chain, 0));
-            SF_TRY(wide(k, first, cnt, 2, false, bs[g]));
+            SF_TRY(wide(k, first, cnt, ngrp, false, bs[g]));
             SF_TRY(sf_exec_event(ex, &e_last[g]));
             SF_HIP(hipEventRecord(e_last[g], bs[g]));
             readers[k & 3].push_back(e_last[g]);

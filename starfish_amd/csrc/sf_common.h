@@ -85,7 +85,6 @@ struct sf_exec {
     int device = -1;
     hipStream_t side = nullptr;  // highest priority: the diagonal-block chain of the Cholesky
     hipStream_t grp[SF_EXEC_GROUPS - 1] = {};  // slab groups 1.. of the fused Cholesky (group 0 = caller's stream)
-    hipStream_t xa = nullptr;    // wide sequence: the launches the next pair's chain waits for (slabs k+2, k+3)
     hipStream_t aux = nullptr;   // banded path: band fill beside the transforms; multi-order calls: the fills
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t* pool = nullptr;
