@@ -648,7 +648,7 @@ struct Layout {
     int m, mpad, M, nf, rows, npad, lda;
 };
 static size_t tilemap_bytes(const Layout& L) {  // per unit: one byte per 128 x 128 tile, as the kernels index it
-    const size_t nt128 = (size_t)(L.npad + 127) / 128;
+    const size_t nt128 = (size_t)(L.npad + 127) / 128;  // (the same count in the frame shifted by 64: npad = 64 mod 128 there)
     return nt128 * nt128;
 }
 static Layout layout_of(const sf_ctx* c) { return Layout{c->m, c->mpad, c->M, c->nf, c->rows, c->npad, c->lda}; }
@@ -901,6 +901,7 @@ static sf_fill_args fill_args(sf_ctx* c, const sf_model_desc* mdl, const double*
     f.loguniform = c->loguniform;
     f.tilemap = nullptr;
     f.nt128 = 0;
+    f.fp = 0;
     f.tilelist = nullptr;
     f.tilecount = nullptr;
     f.list_cap = 0;
@@ -1049,7 +1050,8 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
         f.tilelist = w.tilelist;
         f.tilecount = w.tilecount;
         f.list_cap = (int)tilemap_bytes(layout_of(c));
-        f.nt128 = (c->npad + 127) / 128;
+        f.fp = sf_potrf_front_pad(c->npad, B);  // (the tiles of the factorisation's frame: see sf_potrf_front_pad)
+        f.nt128 = (c->npad + f.fp + 127) / 128;
         rc = sf_launch_fill(f, B, s);
         if (rc) return rc;
     }
@@ -1061,7 +1063,8 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
         gen.mpad = c->mpad;
         gen.ldy = c->npad;
         gen.tilemap = w.tilemap;
-        gen.nt128 = (c->npad + 127) / 128;
+        gen.fp = sf_potrf_front_pad(c->npad, B);
+        gen.nt128 = (c->npad + gen.fp + 127) / 128;
         rc = sf_launch_potrf(w.C, c->npad, c->lda, stride, B, w.info_c, w.ltbuf, w.resid, c->npad, s, &gen, &c->exec);
         if (rc) return rc;
     }
@@ -1157,7 +1160,10 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
     Work W = carve(L, mdl, U, bmax, d_work, work_bytes, true, multi_chunk_cap(U, bmax), 1, SF_MULTI_LANES);
     prof_count_call();
     const int64_t stride = (int64_t)L.npad * L.lda;
-    const int nt128 = (L.npad + 127) / 128;
+    // (one frame for every chunk: the fills run before the chunk sizes are known; a chunk too small for the fused
+    // sequences is factorised by them all the same -- sf_launch_potrf honours the frame of the tile map)
+    const int fp = sf_potrf_front_pad(L.npad, 1 << 20);
+    const int nt128 = (L.npad + fp + 127) / 128;
     // Pipeline: the per-order transform chains and fills (many small launches, a few per cent of the step) run on
     // the context's auxiliary stream one chunk of orders ahead of the factorisation on the caller's stream, so all
     // but the first chunk's are hidden behind the Cholesky of the previous chunk (see multi_first_units).
@@ -1210,6 +1216,7 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
             f.tilecount = w.tilecount;
             f.list_cap = (int)tilemap_bytes(L);
             f.nt128 = nt128;
+            f.fp = fp;
             rc = sf_launch_fill(f, B, sp);
             if (rc) return rc;
         }
@@ -1242,6 +1249,7 @@ extern "C" int sf_loglike_multi_batch(const sf_segment* segs, int nseg, const sf
             gen.ldy = L.npad;
             gen.tilemap = w.tilemap;
             gen.nt128 = nt128;
+            gen.fp = fp;
             rc = sf_launch_potrf(w.C, L.npad, L.lda, stride, ch.units, w.info_c, W.ltbuf, w.resid, L.npad, s, &gen,
                                  &c0->exec_potrf);
             if (rc) return rc;

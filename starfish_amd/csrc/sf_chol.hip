@@ -924,7 +924,9 @@ __global__ __launch_bounds__(NT) void k_diag_mfma(double* __restrict__ T, int64_
 __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, int64_t sT, int pw, int* __restrict__ info,
                                                   int info_off, double* __restrict__ rhs, int ldr,
                                                   double* __restrict__ Cdiag, int ldc, int64_t sC,
-                                                  double* __restrict__ Wt, int64_t sW) {
+                                                  double* __restrict__ Wt, int64_t sW, int fp0) {
+    // fp0: the first fp0 rows / columns of the tile are virtual (identity in T; Cdiag and rhs point fp0 elements BEFORE
+    // the matrix there: never stored, read as zero) -- the first tile of a shifted frame, see sf_potrf_front_pad
     extern __shared__ double dsm[];
     double* Tl = dsm;              // lower blocks (bi >= bj) of the tile at (bi (bi + 1) / 2 + bj) * DBS
     double* El = Tl + 36 * DBS;    // blocks X(e, j), e <= j, of W = L_kk^-T at (j (j + 1) / 2 + e) * DBS
@@ -1034,15 +1036,16 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
     // ---- L -> matrix (lower triangle), Wt[c][j] = (L_kk^-1)[c][j] (block (cb, jb) = X(jb, cb)^T, zero above)
     for (int idx = tid; idx < nb * nb * 256; idx += 512) {
         const int blk = idx >> 8, bi = blk / nb, bj = blk - bi * nb, r = (idx >> 4) & 15, c = idx & 15;
-        if (bj < bi || (bj == bi && c <= r)) Cb[(int64_t)(16 * bi + r) * ldc + 16 * bj + c] = Tl[tb(bi, bj) + r * DLD + c];
+        if ((bj < bi || (bj == bi && c <= r)) && 16 * bj + c >= fp0)
+            Cb[(int64_t)(16 * bi + r) * ldc + 16 * bj + c] = Tl[tb(bi, bj) + r * DLD + c];
         Wb[(int64_t)(16 * bi + r) * SF_LDT + 16 * bj + c] = bj <= bi ? El[eb(bj, bi) + c * DLD + r] : 0.0;
     }
     // ---- z_k = L_kk^-1 r_k with the explicit inverse
     if (rhs) {
         double* rb = rhs + (int64_t)b * ldr;
-        if (tid < pw) rz[tid] = rb[tid];
+        if (tid < pw) rz[tid] = tid >= fp0 ? rb[tid] : 0.0;
         __syncthreads();
-        if (tid < pw) {
+        if (tid < pw && tid >= fp0) {
             const int i = tid, ibk = i >> 4, ir = i & 15;
             double zacc = 0.0;
             for (int j = 0; j <= i; ++j) zacc = __builtin_fma(El[eb(j >> 4, ibk) + (j & 15) * DLD + ir], rz[j], zacc);
@@ -1052,9 +1055,9 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
 }
 #define SF_DIAG_LDS_BYTES ((73 * DBS + 128) * sizeof(double))
 static int sf_launch_diag128(double* T, int64_t sT, int pw, int* info, int info_off, double* rhs, int ldr, double* Cdiag,
-                             int ldc, int64_t sC, double* Wt, int64_t sW, int batch, hipStream_t s) {
+                             int ldc, int64_t sC, double* Wt, int64_t sW, int batch, hipStream_t s, int fp0 = 0) {
     static const bool scratch = SF_TUNE_FLAG("SF_DIAG_SCRATCH");  // tuning aid: the L2-resident k_diag_mfma<512>
-    if (scratch) {
+    if (scratch && fp0 == 0) {
         hipLaunchKernelGGL(k_diag_mfma<512>, dim3(batch), dim3(512), 0, s, T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc, sC, Wt, sW);
     } else {
         static sf_dev_once attr_once;  // devices whose function attributes are set
@@ -1063,7 +1066,7 @@ static int sf_launch_diag128(double* T, int64_t sT, int pw, int* info, int info_
             return SF_OK;
         }));
         hipLaunchKernelGGL(k_diag_lds, dim3(batch), dim3(512), SF_DIAG_LDS_BYTES, s, T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc,
-                           sC, Wt, sW);
+                           sC, Wt, sW, fp0);
     }
     SF_LAUNCH_CHECK();
     return SF_OK;
@@ -1114,6 +1117,10 @@ struct sf_panel_args {
     // the diagonal, so the K loop of a slab starts at its first non-zero column; rows >= nband (the border: dense
     // rows that ride along) form one extra slab at xrow0, the last of the launch.  All 0 for dense matrices.
     int kband, nband, xrow0;
+    // shifted frame (sf_potrf_front_pad): C, rhs and genY point fp (lda + 1) / fp / fp elements BEFORE the data, n / k0 /
+    // row0 / the tile map count in that frame.  Rows and columns < fp are virtual (identity): every K loop starts at
+    // column fp, the panel-0 accesses that would touch a virtual column are predicated.  0 for unshifted matrices.
+    int fp;
 };
 
 // granule swizzle of the main loop's LDS image (see k_chol_panel)
@@ -1157,6 +1164,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
     const int row0 = (g.xrow0 && sl == g.nslab - 1) ? g.xrow0 : g.row0 + sl * g.slab_step * GT;
     const int rows_here = min(GT, ((g.nband && row0 < g.nband) ? g.nband : g.n) - row0);
     const int pw = g.pw, k0 = g.k0;
+    const int cfp = k0 == 0 ? g.fp : 0;  // panel columns below cfp are virtual (zero below the diagonal tile)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1224,7 +1232,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         const int nk_all = SF_PANEL_SKIPS(g, 4) ? 0 : k0 / GK;
         // band: the K loop starts at the first column where both operands can be non-zero (a band slab's own rows;
         // for the dense border rows the panel's rows decide -- what lies left of that was never even written)
-        const int klo = g.kband ? min(max((row0 < g.nband ? row0 : k0) - g.kband, 0) / GK, nk_all) : 0;
+        const int klo = g.kband ? min(max((row0 < g.nband ? row0 : k0) - g.kband, 0) / GK, nk_all) : min(g.fp / GK, nk_all);
         const int kbeg = MODE == 1 ? min(klo + sp * g.kchunk, nk_all) : klo;
         const int kend = MODE == 1 ? min(kbeg + g.kchunk, nk_all) : (MODE == 2 ? kbeg : nk_all);
         const int nk = kend - kbeg;
@@ -1266,9 +1274,9 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
                 const double* yk = Yb + (int64_t)(kk + lq) * g.ldy;
                 double ya[TM], yb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) ya[i] = yk[min(gr + i * 16, g.ldy - 1)];
+                for (int i = 0; i < TM; ++i) ya[i] = yk[min(gr + i * 16, g.ldy + g.fp - 1)];
 #pragma unroll
-                for (int i = 0; i < TN; ++i) yb[i] = yk[min(gc + i * 16, g.ldy - 1)];
+                for (int i = 0; i < TN; ++i) yb[i] = gc + i * 16 >= cfp ? yk[min(gc + i * 16, g.ldy + g.fp - 1)] : 0.0;
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -1286,7 +1294,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
                     for (int r = 0; r < 4; ++r) {
                         const int row = wm * (16 * TM) + mi * 16 + lq + 4 * r;
                         double v = 0.0;
-                        if (row < rows_here && col < pw) v = Cin[(int64_t)row * g.lda + col];
+                        if (row < rows_here && col < pw && col >= cfp) v = Cin[(int64_t)row * g.lda + col];
                         acc[mi][ni][r] = v;
                     }
                 }
@@ -1469,7 +1477,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = wm * (16 * TM) + mi * 16 + lq + 4 * r;
-                    if (row < rows_here && col < pw) Lout[(int64_t)row * g.lda + col] = acc[mi][ni][r];
+                    if (row < rows_here && col < pw && col >= cfp) Lout[(int64_t)row * g.lda + col] = acc[mi][ni][r];
                 }
             }
         if (RHS && g.rhs) {
@@ -1478,7 +1486,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
                 const int col = wn * (16 * TN) + ni * 16 + l15;
-                zc[ni] = col < pw ? z[col] : 0.0;
+                zc[ni] = (col < pw && col >= cfp) ? z[col] : 0.0;
             }
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
@@ -1524,7 +1532,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         double2 rl[2];
         auto gload2 = [&](int kt) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) rl[q] = *(const double2*)(Lp[q] + kt * GK);
+            for (int q = 0; q < 2; ++q) rl[q] = kt * GK + lc >= cfp ? *(const double2*)(Lp[q] + kt * GK) : make_double2(0.0, 0.0);
         };
         auto lstore2 = [&](int buf) {
 #pragma unroll
@@ -1543,7 +1551,10 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
-                acc2[q][r] = (q < nstore && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
+                if (row0 + min(row, col) < g.fp)  // virtual rows / columns of the first tile: identity
+                    acc2[q][r] = row == col ? 1.0 : 0.0;
+                else
+                    acc2[q][r] = (q < nstore && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
             }
         if (nk2 > 0) lstore2(0);
         __syncthreads();
@@ -1624,6 +1635,7 @@ struct sf_panelw_args {
     const unsigned char* tilemap;
     int64_t sY;
     int ldy, mpad, nt128;
+    int fp;            // shifted frame, see sf_panel_args
 };
 
 template <bool RHS>
@@ -1638,6 +1650,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
     const int row0 = g.row0 + sl * g.slab_step * GT;
     const int rows_here = min(GT, g.n - row0);
     const int k0 = g.k0;
+    const int cfp = k0 == 0 ? g.fp : 0;  // pair columns below cfp are virtual (zero below the diagonal tile)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1665,7 +1678,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
             const bool isA = G < 16;
             const int r = (isA ? G : G - 16) * 8 + grow;
             const int c = gpos ^ sf_swz(r);
-            src[j] = Cb + (int64_t)(isA ? row0 + min(r, rows_here - 1) : k0 + r) * g.lda + 2 * c;
+            src[j] = Cb + (int64_t)(isA ? row0 + min(r, rows_here - 1) : k0 + r) * g.lda + g.fp + 2 * c;  // (K starts at column fp)
         }
         auto glds16 = [&](const double* p, unsigned lds_dst) {
             unsigned keep;
@@ -1679,7 +1692,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
             for (int j = 0; j < 3; ++j) glds16(src[j] + kt * GK, lds0 + (unsigned)(stage * WST * 8 + (3 * w + j) * 1024));
         };
         auto gwait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-        const int nk = k0 / GK;
+        const int nk = max(k0 - g.fp, 0) / GK;
         if (nk > 0) gload(0, 0);
         if (nk > 1) gload(1, 1);
 
@@ -1704,9 +1717,9 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
                     const double* yk = Yb + (int64_t)(kk + lq) * g.ldy;
                     double ya[TM], yb[2];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) ya[i] = yk[min(gr + i * 16, g.ldy - 1)];
+                    for (int i = 0; i < TM; ++i) ya[i] = yk[min(gr + i * 16, g.ldy + g.fp - 1)];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) yb[i] = yk[min(gc + i * 16, g.ldy - 1)];
+                    for (int i = 0; i < 2; ++i) yb[i] = gc + i * 16 >= cfp ? yk[min(gc + i * 16, g.ldy + g.fp - 1)] : 0.0;
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -1723,7 +1736,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = wm * 32 + mi * 16 + lq + 4 * r;
-                            acc[mi][2 * hf + nn][r] = row < rows_here ? Cin[(int64_t)row * g.lda + col] : 0.0;
+                            acc[mi][2 * hf + nn][r] = (row < rows_here && col >= cfp) ? Cin[(int64_t)row * g.lda + col] : 0.0;
                         }
                     }
             }
@@ -1845,8 +1858,9 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
         double* Bc = Bs;  // [128][CLD]
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double2 l0 = *(const double2*)(L21 + q * 32);
-            const double2 l1 = *(const double2*)(L21 + q * 32 + 2);
+            const bool real = (tid & 7) * 4 + q * 32 >= cfp;
+            const double2 l0 = real ? *(const double2*)(L21 + q * 32) : make_double2(0.0, 0.0);
+            const double2 l1 = real ? *(const double2*)(L21 + q * 32 + 2) : make_double2(0.0, 0.0);
             __syncthreads();  // previous chunk consumed
             if (wn == q) {
 #pragma unroll
@@ -1897,14 +1911,14 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = wm * 32 + mi * 16 + lq + 4 * r;
-                    if (row < rows_here) Lout[(int64_t)row * g.lda + col] = acc[mi][ni][r];
+                    if (row < rows_here && col >= cfp) Lout[(int64_t)row * g.lda + col] = acc[mi][ni][r];
                 }
             }
         if (RHS && g.rhs) {
             const double* z = g.rhs + (int64_t)b * g.ldr + k0;
             double zc[TN];
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) zc[ni] = z[WBC(ni) + l15];
+            for (int ni = 0; ni < TN; ++ni) zc[ni] = WBC(ni) + l15 >= cfp ? z[WBC(ni) + l15] : 0.0;
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -2229,6 +2243,18 @@ static int sf_launch_potrf_v1(double* A, int n, int lda, int64_t stride, int bat
     return SF_OK;
 }
 
+// The fused sequences work in the frame of sf_potrf_front_pad: from here on A / rhs point fp (lda + 1) / fp elements before
+// the data and n counts the fp virtual leading rows too (the scratch layout above is sized with the real n).
+#define SF_SHIFT_FRAME()                                                              \
+    do {                                                                              \
+        if (fp != 0 && (fp != 64 || n % GT != 64)) {                                  \
+            sf_set_error("potrf: front pad %d does not fit n = %d", fp, n);           \
+            return SF_EINVAL;                                                         \
+        }                                                                             \
+        A -= (int64_t)fp * (lda + 1);                                                 \
+        if (rhs) rhs -= fp;                                                           \
+        n += fp;                                                                      \
+    } while (0)
 static std::atomic<int> g_chol_sequence{-1};
 int sf_set_cholesky_sequence(int mode) {
     if (mode < -1 || mode > 3) {
@@ -2249,7 +2275,7 @@ int sf_set_cholesky_sequence(int mode) {
 // workgroups the other groups keep the CUs full (one launch per panel left 0.25-0.75 of a round of 512
 // workgroups idle at every panel boundary).
 static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
-                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
+                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex, int fp) {
     if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
         sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
         return SF_EINVAL;
@@ -2258,6 +2284,7 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
     const int64_t sT = (int64_t)(n + SF_NB) * SF_LDT + SF_TSKEW;  // (layout shared with the unfused path)
     double* Wt2 = T + (size_t)batch * sT;
     const int64_t sW = (int64_t)SF_NB * SF_LDT + SF_TSKEW;
+    SF_SHIFT_FRAME();
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
     SF_TRY(sf_exec_prepare(ex));
     static const bool no_lookahead = SF_TUNE_FLAG("SF_NO_LOOKAHEAD");
@@ -2300,8 +2327,9 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
             g.sS = sT;
             g.ldS = SF_LDT;
         }
+        g.fp = fp;
         if (gen) {
-            g.genY = gen->Y;
+            g.genY = gen->Y - fp;
             g.sY = (int64_t)gen->mpad * gen->ldy;
             g.ldy = gen->ldy;
             g.mpad = gen->mpad;
@@ -2319,9 +2347,9 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
             const int r0 = row0 + i * step * GT;
             rows += (n - r0 < GT) ? n - r0 : GT;
         }
-        const double flops_main = 2.0 * k0 * rows * pw * batch;
+        const double flops_main = 2.0 * (k0 > fp ? k0 - fp : 0) * rows * pw * batch;
         const double flops_epi = (rows * pw * (double)pw + (double)GT * rows * pw) * batch;
-        const int nk = k0 / GK;
+        const int nk = (k0 > fp ? k0 - fp : 0) / GK;
         const int S = pw > 0 ? sf_split_policy(nblk, nk) : 1;
         void* tok;  // (every kernel launch is one profiled launch: what rocprofv3 --stats counts)
         if (S > 1) {
@@ -2361,8 +2389,8 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
         if (c != s || G > 1)
             for (int g = 0; g < G; ++g)
                 if (e_rest_prev[g] && (c != gs[g])) SF_HIP(hipStreamWaitEvent(c, e_rest_prev[g], 0));
-        SF_TRY(sf_launch_diag128(T, sT, pw, info, k0, rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW,
-                                 batch, c));
+        SF_TRY(sf_launch_diag128(T, sT, pw, info, k0 - fp, rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wt, sW,
+                                 batch, c, k == 0 ? fp : 0));
         if (k + 1 >= nt) break;
         hipEvent_t e_d;
         SF_TRY(sf_exec_event(ex, &e_d));
@@ -2409,7 +2437,7 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
 // tail_rounds: the pairs whose wide launches have at most this many rounds of workgroups left (and everything after them)
 // are single narrow steps; -1 = wide to the end; -2 = switch half-way (test aid: exercises the hand-over on any size).
 static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
-                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex, int tail_rounds) {
+                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex, int tail_rounds, int fp) {
     if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
         sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
         return SF_EINVAL;
@@ -2426,6 +2454,7 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
     const int64_t sW = (int64_t)SF_NB * SF_LDT + SF_TSKEW;
     auto Wslot = [&](int k) { return Wt2 + (size_t)((k >> 1) & 1) * batch * sW + (size_t)(k & 1) * GT * SF_LDT; };
     double* part = Wt2 + 2 * (size_t)batch * sW + 64;
+    SF_SHIFT_FRAME();
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
     SF_TRY(sf_exec_prepare(ex));
     // A(p) sits between chain(p) and chain(p+1) anyway: it shares the chain's stream.  A stream of its own made a cfg-2
@@ -2462,8 +2491,9 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
             g.sS = sT;
             g.ldS = SF_LDT;
         }
+        g.fp = fp;
         if (gen) {
-            g.genY = gen->Y;
+            g.genY = gen->Y - fp;
             g.sY = (int64_t)gen->mpad * gen->ldy;
             g.ldy = gen->ldy;
             g.mpad = gen->mpad;
@@ -2473,9 +2503,9 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         const long long nblk = (long long)nslab * batch;
         double rows = 0.0;
         for (int i = 0; i < nslab; ++i) rows += (n - (row0 + i * step * GT) < GT) ? n - (row0 + i * step * GT) : GT;
-        const double flops_main = 2.0 * k0 * rows * pw * batch;
+        const double flops_main = 2.0 * (k0 > fp ? k0 - fp : 0) * rows * pw * batch;
         const double flops_epi = (rows * pw * (double)pw + (double)GT * rows * pw) * batch;
-        const int nk = k0 / GK;
+        const int nk = (k0 > fp ? k0 - fp : 0) / GK;
         const int S = pw > 0 ? sf_split_policy(nblk, nk) : 1;
         void* tok;
         if (S > 1) {
@@ -2522,8 +2552,9 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
             g.sS = sT;
             g.ldS = SF_LDT;
         }
+        g.fp = fp;
         if (gen) {
-            g.genY = gen->Y;
+            g.genY = gen->Y - fp;
             g.sY = (int64_t)gen->mpad * gen->ldy;
             g.ldy = gen->ldy;
             g.mpad = gen->mpad;
@@ -2539,7 +2570,8 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         for (int i = 0; i < nslab; ++i) rows += (n - (slab0 + i * step) * GT < GT) ? n - (slab0 + i * step) * GT : GT;
         // algorithmic flops of the two panel steps it replaces: update 2 k0 rows 128 (+ 128 more K for the second panel),
         // solves rows 128^2 each, symmetric rank-128 updates of the lower tiles
-        const double flops = (2.0 * g.k0 * rows * GT + 2.0 * (g.k0 + GT) * rows * GT + 2.0 * (rows * GT * (double)GT + (double)GT * rows * GT)) * batch;
+        const double kk = g.k0 > fp ? g.k0 - fp : 0;
+        const double flops = (2.0 * kk * rows * GT + 2.0 * (kk + GT) * rows * GT + 2.0 * (rows * GT * (double)GT + (double)GT * rows * GT)) * batch;
         void* tok;
         sf_prof_gemm_begin(st, flops, &tok);
         if (rhs)
@@ -2553,8 +2585,8 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
     auto diag = [&](int k) -> int {
         const int k0 = k * GT;
         const int pw = (n - k0 < GT) ? n - k0 : GT;
-        return sf_launch_diag128(T, sT, pw, info, k0, rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wslot(k), sW,
-                                 batch, c);
+        return sf_launch_diag128(T, sT, pw, info, k0 - fp, rhs ? rhs + k0 : nullptr, ldr, A + (int64_t)k0 * lda + k0, lda, stride, Wslot(k), sW,
+                                 batch, c, k == 0 ? fp : 0);
     };
 
     SF_TRY(narrow(0, 0, 0, 1, 1, nullptr, true, c, 0));  // diagonal tile 0 goes to the scratch unchanged
@@ -2778,6 +2810,15 @@ int sf_launch_potrf_band(int n, int nband, int halfwidth, int batch, const doubl
     return SF_OK;
 }
 
+int sf_potrf_front_pad(int n, int batch) {
+    static const bool off = SF_TUNE_FLAG("SF_NO_FRONT_PAD");  // tuning aid: A/B of the shifted frame
+    static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");
+    const int sel = g_chol_sequence.load();
+    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < 28);  // (as in sf_launch_potrf)
+    if (off || v1 || n % GT != 64 || n < 2 * GT) return 0;
+    return 64;
+}
+
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
                     double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
     // The fused panel kernel (128-column panels) is the faster sequence once the batch fills the chip; small batches
@@ -2797,10 +2838,12 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     if (!ex) ex = sf_exec_thread_local();
     static const int tail_env = SF_TUNE_INT("SF_WIDE_TAIL_ROUNDS", -1);  // measured at cfg 2: -1 (wide to the end) 49.3 ms, 2: 50.0, 5: 50.4, 8: 51.0, 12: 51.8 (narrow: 51.5)
     const bool v3h = sel == 3;  // (test aid) wide pairs for the first half of the panels, narrow steps after
+    // frame of the fused sequences: the caller's (whose tile map was built in it) or this call's own
+    const int fp = gen ? gen->fp : sf_potrf_front_pad(n, batch);
     if (v3 || v3h)
-        return sf_launch_potrf_v3(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex, v3h ? -2 : (sel == 2 ? -1 : tail_env));
-    return v1 ? sf_launch_potrf_v1(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex)
-              : sf_launch_potrf_v2(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
+        return sf_launch_potrf_v3(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex, v3h ? -2 : (sel == 2 ? -1 : tail_env), fp);
+    if (v1 && fp == 0) return sf_launch_potrf_v1(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
+    return sf_launch_potrf_v2(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex, fp);
 }
 
 int sf_launch_logdet_sqmah(const double* L, int n, int lda, int64_t stride, int batch, const double* R,

@@ -111,7 +111,15 @@ struct sf_gen_args {
     int mpad, ldy;
     const unsigned char* tilemap;  // [batch][nt128 * nt128]
     int nt128;
+    int fp;  // front pad the tile map was built for (sf_potrf_front_pad): tiles are those of the SHIFTED frame
 };
+// Orders whose padded size is an odd multiple of 64 (3008 = 23.5 slabs of 128 rows) are factorised in a frame shifted by
+// `fp` = 64 virtual identity rows / columns IN FRONT: the half-empty slab becomes the first one, whose workgroups have
+// the shortest K loops, instead of the last one with the longest (cfg 3: 6 % of the chip's time).  Nothing moves in
+// memory: the kernels address the matrix from a base pointer fp (lda + 1) elements earlier, skip the fp leading columns
+// of every K loop (they hold zeros below the diagonal block) and predicate the few accesses of the first tile row /
+// column that would touch the virtual part.  0 = frame not shifted (n a multiple of 128, or the unfused sequence).
+int sf_potrf_front_pad(int n, int batch);
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
                     double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen = nullptr, sf_exec* ex = nullptr);
 int sf_band_tiles_lda(int nband);
@@ -144,6 +152,7 @@ struct sf_fill_args {
     int loguniform;        // wave_i = wave_0 e^(i delta) to rounding -> K_global depends on i-j only
     unsigned char* tilemap; // optional [B][nt128*nt128]: 1 = the 128x128 tile is materialised in C
     int nt128;
+    int fp;                // 0 or 64: the tile map / list index the tiles of the factorisation's shifted frame (sf_potrf_front_pad)
     // optional compact work list of the materialised tiles (likelihood path): k_tile_map appends (tm << 8 | tn) per flagged
     // 128 x 128 tile, the fill then launches a few workgroups per walker that walk the list instead of one (mostly empty)
     // workgroup per 64 x 64 tile of the whole matrix

@@ -56,11 +56,13 @@ __global__ __launch_bounds__(256) void k_tile_map(sf_fill_args a) {
     const int tm = e / nt, tn = e - tm * nt;
     unsigned char flag = 0;
     if (tn <= tm) {
-        const int rlo = tm * 128, clo = tn * 128;
-        if (rlo / SF_NB == clo / SF_NB || rlo >= a.n) {
+        // tile (tm, tn) of the factorisation's frame = rows 128 tm - fp .. of the matrix (a.fp leading virtual rows)
+        const int vr = tm * 128, vc = tn * 128;
+        const int rlo = max(vr - a.fp, 0), clo = max(vc - a.fp, 0);
+        if (vr / SF_NB == vc / SF_NB || rlo >= a.n) {
             flag = 1;  // diagonal block (or pure padding rows)
         } else {
-            const int rhi = min(rlo + 127, a.n - 1), chi = min(clo + 127, a.n - 1);
+            const int rhi = min(vr - a.fp + 127, a.n - 1), chi = min(vc - a.fp + 127, a.n - 1);
             const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
             if (a.has_global) {
                 if (!a.monotonic) flag = 1;
@@ -98,7 +100,10 @@ __global__ __launch_bounds__(256) void k_tile_map(sf_fill_args a) {
 template <bool BAND>
 __device__ __forceinline__ void sf_fill_tile(const sf_fill_args& a, int b, int tm, int tn) {
     if (a.lower_only && tn > tm) return;
-    if (a.tilemap && !a.tilemap[(int64_t)b * a.nt128 * a.nt128 + (tm >> 1) * a.nt128 + (tn >> 1)]) return;
+    if (a.tilemap) {  // (tm, tn) count 64-row tiles of the MATRIX; the map is indexed in the factorisation's frame
+        const int fs = a.fp >> 6;
+        if (!a.tilemap[(int64_t)b * a.nt128 * a.nt128 + ((tm + fs) >> 1) * a.nt128 + ((tn + fs) >> 1)]) return;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
@@ -262,9 +267,11 @@ __global__ __launch_bounds__(256, BAND ? 2 : 4) void k_fill_tiles_list(sf_fill_a
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int cnt = min(a.tilecount[b], a.list_cap) * 4;
     const unsigned short* __restrict__ list = a.tilelist + (int64_t)b * a.list_cap;
+    const int fs = a.fp >> 6;  // the list holds tiles of the factorisation's frame: a.fp / 64 virtual 64-row tiles in front
     for (int li = g; li < cnt; li += G) {
         const int e = list[li >> 2];
-        sf_fill_tile<BAND>(a, b, 2 * (e >> 8) + ((li >> 1) & 1), 2 * (e & 255) + (li & 1));
+        const int tm = 2 * (e >> 8) + ((li >> 1) & 1) - fs, tn = 2 * (e & 255) + (li & 1) - fs;
+        if (tm >= 0 && tn >= 0) sf_fill_tile<BAND>(a, b, tm, tn);
     }
 }
 
@@ -273,6 +280,10 @@ __global__ void k_band_gtab(sf_fill_args a, double* __restrict__ gtab, int ws);
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
     if (a.n_local > SF_MAX_LOCAL) {
         sf_set_error("at most %d local kernels are supported", SF_MAX_LOCAL);
+        return SF_EINVAL;
+    }
+    if (a.fp != 0 && (a.fp != 64 || !a.tilemap || !a.lower_only)) {
+        sf_set_error("fill: a shifted tile frame needs fp = 64, a tile map and lower_only");
         return SF_EINVAL;
     }
     const int nout = a.lower_only ? a.npad : a.n;

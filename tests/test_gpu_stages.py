@@ -138,6 +138,19 @@ def test_potrf_reports_non_positive_pivot(gpu, chol_sequence):
     _lib.check(gpu.sf_potrf_batch(D.ptr(dA), n, lda, n * lda, 2, D.ptr(info), D.ptr(ws), ws.numel(),
                                   D.stream_ptr(dev)))
     assert info.cpu().numpy().tolist() == [0, 71]
+    # n = 64 mod 128: the fused sequences factorise in a frame shifted by 64 virtual rows (sf_potrf_front_pad); the pivot
+    # index reported is the matrix's own, in the first tile (which holds the virtual rows) and after it
+    n, lda = 320, 336
+    A = np.zeros((3, n, lda))
+    A[:, :, :n] = np.eye(n)
+    A[1, 5, 5] = -1.0
+    A[2, 200, 200] = -1.0
+    dA = D.to_dev(A, dev)
+    info = D.empty((3,), dev, torch.int32)
+    ws = D.workspace(gpu.sf_potrf_workspace_bytes(n, 3), dev)
+    _lib.check(gpu.sf_potrf_batch(D.ptr(dA), n, lda, n * lda, 3, D.ptr(info), D.ptr(ws), ws.numel(),
+                                  D.stream_ptr(dev)))
+    assert info.cpu().numpy().tolist() == [0, 6, 201]
 
 
 @pytest.mark.parametrize("tag,m", [("a", 8), ("b", 4)])
