@@ -126,7 +126,7 @@ int sf_extinct(const double* d_wave, int n, const double* d_flux, int rows, doub
 /* scipy.linalg.cho_factor call site Starfish/models/spectrum_model.py:400 (LAPACK dpotrf).
  * In-place batched lower Cholesky of `batch` matrices, matrix b at d_A + b*stride (doubles),
  * n must be a multiple of 64 (callers pad with an identity block), row stride lda.
- * d_work: sf_potrf_workspace_bytes(n, batch).  d_info[batch]. */
+ * d_work: sf_potrf_workspace_bytes(n, batch).  d_info[batch]: 0, or the 1-based index of the first non-positive pivot. */
 int sf_potrf_batch(double* d_A, int n, int lda, int64_t stride, int batch, int* d_info,
                    void* d_work, size_t work_bytes, void* stream);
 size_t sf_potrf_workspace_bytes(int n, int batch);
@@ -327,10 +327,13 @@ int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, const doubl
 
 /* Tuning / test aid (process-global): the batched Cholesky has three launch sequences -- the fused panel kernel
  * (128-column panels, two workgroups per CU; the default once the batch fills the chip), the unfused one (256-column
- * panels, separate panel-solve and diagonal-update launches; fewer sequential steps, faster for batches below ~28
+ * panels, separate panel-solve and diagonal-update launches; fewer sequential steps, taken for batches below 20
  * matrices) and the wide one (pairs of panels, one 16-wave workgroup per CU keeps a 128 x 256 tile: a third less HBM
- * traffic; taken for full batches, 96-512 matrices of 2048-8192 rows).
- * mode -1 = choose by batch and matrix size (default), 0 = always fused, 1 = always unfused, 2 = always wide.
+ * traffic; taken for batches of 96 or more matrices of 2048 or more rows).
+ * mode -1 = choose by batch and matrix size (default), 0 = always fused, 1 = always unfused, 2 = always wide,
+ * 3 = wide for the first half of the panels, then fused (test aid: exercises the hand-over between the two).
+ * The fused and wide sequences factorise matrices of 64 mod 128 rows in a frame shifted by 64 virtual identity rows
+ * (addressing only: nothing moves in memory, the caller's layout and the pivot index reported in d_info are unchanged).
  * Same results to rounding. */
 int sf_debug_cholesky_sequence(int mode);
 

@@ -2016,6 +2016,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
 // time of a launch is the time of ONE workgroup's K loop.  S is a power of two, every part keeps >= 8 slabs.
 #define SF_CHIP_WGS 512
 #define SF_SPLIT_MAX 8
+static size_t sf_split_region_tiles(void) { return 2 * SF_CHIP_WGS; }  // partial-sum tiles per region
 static int sf_split_policy(long long wgs, int nk) {
     static const int force = SF_TUNE_INT("SF_CHOL_SPLIT", -1);  // tuning aid
     int S = 1;
@@ -2027,7 +2028,6 @@ static int sf_split_policy(long long wgs, int nk) {
     return S;
 }
 // partial-sum tiles: one region for the chain (top) launches, one per slab group
-static size_t sf_split_region_tiles(void) { return 2 * SF_CHIP_WGS; }
 size_t sf_potrf_work_doubles(int n, int batch) {
     const size_t b = (size_t)batch;
     return b * SF_LTB_DOUBLES + b * ((size_t)(n + SF_NB) * SF_LDT + SF_TSKEW) + 2 * b * ((size_t)SF_NB * SF_LDT + SF_TSKEW) + 64 +
@@ -2302,8 +2302,11 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
 
     double* part = Wt2 + 2 * (size_t)batch * sW + 64;  // split-K partial sums: region 0 = chain, 1 + g = group g
     const int nt = (n + GT - 1) / GT;
+    // phase 0: the whole step; 1 / 2: only the split-K partial sums / only what follows them (the chain runs the partial
+    // sums of top(k), which do not need D(k), beside D(k) on another stream); split_of() tells whether the step is split
+    auto split_of = [&](int k0, int pw, long long nblk) { return pw > 0 ? sf_split_policy(nblk, (k0 > fp ? k0 - fp : 0) / GK) : 1; };
     auto launch_panel = [&](int k0, int pw, int row0, int nslab, int step, const double* Wt, bool to_scratch,
-                            hipStream_t st, int region) -> int {
+                            hipStream_t st, int region, int phase) -> int {
         sf_panel_args g = {};
         g.C = A;
         g.sC = stride;
@@ -2350,21 +2353,25 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
         const double flops_main = 2.0 * (k0 > fp ? k0 - fp : 0) * rows * pw * batch;
         const double flops_epi = (rows * pw * (double)pw + (double)GT * rows * pw) * batch;
         const int nk = (k0 > fp ? k0 - fp : 0) / GK;
-        const int S = pw > 0 ? sf_split_policy(nblk, nk) : 1;
+        const int S = split_of(k0, pw, nblk);
         void* tok;  // (every kernel launch is one profiled launch: what rocprofv3 --stats counts)
         if (S > 1) {
             g.ksplit = S;
             g.kchunk = (nk + S - 1) / S;
             g.part = part + (size_t)region * sf_split_region_tiles() * (GT * GT);
-            sf_prof_gemm_begin(st, flops_main, &tok);
-            hipLaunchKernelGGL((k_chol_panel<false, 1>), dim3((unsigned)(nblk * S)), dim3(512), 0, st, g);
-            sf_prof_gemm_end(tok);
-            sf_prof_gemm_begin(st, flops_epi, &tok);
-            if (rhs)
-                hipLaunchKernelGGL((k_chol_panel<true, 2>), dim3((unsigned)nblk), dim3(512), 0, st, g);
-            else
-                hipLaunchKernelGGL((k_chol_panel<false, 2>), dim3((unsigned)nblk), dim3(512), 0, st, g);
-            sf_prof_gemm_end(tok);
+            if (phase != 2) {
+                sf_prof_gemm_begin(st, flops_main, &tok);
+                hipLaunchKernelGGL((k_chol_panel<false, 1>), dim3((unsigned)(nblk * S)), dim3(512), 0, st, g);
+                sf_prof_gemm_end(tok);
+            }
+            if (phase != 1) {
+                sf_prof_gemm_begin(st, flops_epi, &tok);
+                if (rhs)
+                    hipLaunchKernelGGL((k_chol_panel<true, 2>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+                else
+                    hipLaunchKernelGGL((k_chol_panel<false, 2>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+                sf_prof_gemm_end(tok);
+            }
         } else {
             sf_prof_gemm_begin(st, flops_main + flops_epi, &tok);
             if (rhs)
@@ -2378,7 +2385,9 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
     };
 
     // diagonal tile 0 goes to the scratch unchanged
-    SF_TRY(launch_panel(0, 0, 0, 1, 1, nullptr, true, c, 0));
+    SF_TRY(launch_panel(0, 0, 0, 1, 1, nullptr, true, c, 0, 0));
+    static const bool part_on_chain = SF_TUNE_FLAG("SF_PART_ON_CHAIN");  // tuning aid: the partial sums of top(k) after D(k) on the chain
+    hipEvent_t e_epi = nullptr;                   // end of top(k-1) on the chain
     hipEvent_t e_rest[SF_EXEC_GROUPS] = {};       // last launch of every group
     hipEvent_t e_rest_prev[SF_EXEC_GROUPS] = {};  // ... one panel earlier (their readers of Wt[panel & 1])
     for (int k = 0; k < nt; ++k) {
@@ -2395,12 +2404,30 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
         hipEvent_t e_d;
         SF_TRY(sf_exec_event(ex, &e_d));
         SF_HIP(hipEventRecord(e_d, c));
-        // top(k): the slab of the next diagonal tile, on the chain; its row was finished by the group of slab k+1
+        // top(k): the slab of the next diagonal tile, on the chain; its row was finished by the group of slab k+1.
+        // Its long-K part (split-K partial sums) needs the rows of slabs k and k+1 left of the panel, not D(k): when the
+        // step is split it runs BESIDE D(k), on the stream of the group of slab k+1 (whose last launch it waits for
+        // anyway) -- the chain is D(k) | partial sums -> reduce + solve + diagonal tile -> D(k+1).
         {
+            hipStream_t gk = gs[(k + 1) % G];
             hipEvent_t dep = e_rest[(k + 1) % G];
-            if (dep && c != gs[(k + 1) % G]) SF_HIP(hipStreamWaitEvent(c, dep, 0));
+            if (c != gk && !part_on_chain && split_of(k0, pw, batch) > 1) {
+                if (e_epi) SF_HIP(hipStreamWaitEvent(gk, e_epi, 0));  // row k's columns of panel k-1; the partial-sum region
+                SF_TRY(launch_panel(k0, pw, (k + 1) * GT, 1, 1, Wt, true, gk, 0, 1));
+                hipEvent_t e_part;
+                SF_TRY(sf_exec_event(ex, &e_part));
+                SF_HIP(hipEventRecord(e_part, gk));
+                SF_HIP(hipStreamWaitEvent(c, e_part, 0));
+                SF_TRY(launch_panel(k0, pw, (k + 1) * GT, 1, 1, Wt, true, c, 0, 2));
+            } else {
+                if (dep && c != gk) SF_HIP(hipStreamWaitEvent(c, dep, 0));
+                SF_TRY(launch_panel(k0, pw, (k + 1) * GT, 1, 1, Wt, true, c, 0, 0));
+            }
+            if (c != s) {
+                SF_TRY(sf_exec_event(ex, &e_epi));
+                SF_HIP(hipEventRecord(e_epi, c));
+            }
         }
-        SF_TRY(launch_panel(k0, pw, (k + 1) * GT, 1, 1, Wt, true, c, 0));
         // rest(k): slabs k+2 .. nt-1, slab i on the stream of group i mod G
         for (int g = 0; g < G; ++g) e_rest_prev[g] = e_rest[g];
         for (int g = 0; g < G; ++g) {
@@ -2409,7 +2436,7 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
             if (first >= nt) continue;
             const int cnt = (nt - 1 - first) / G + 1;
             if (gs[g] != c) SF_HIP(hipStreamWaitEvent(gs[g], e_d, 0));
-            SF_TRY(launch_panel(k0, pw, first * GT, cnt, G, Wt, false, gs[g], 1 + g));
+            SF_TRY(launch_panel(k0, pw, first * GT, cnt, G, Wt, false, gs[g], 1 + g, 0));
             SF_TRY(sf_exec_event(ex, &e_rest[g]));
             SF_HIP(hipEventRecord(e_rest[g], gs[g]));
         }
@@ -2810,24 +2837,25 @@ int sf_launch_potrf_band(int n, int nband, int halfwidth, int batch, const doubl
     return SF_OK;
 }
 
+// Small batches are bound by the number of sequential long-K steps; the unfused sequence has half as many (256-column
+// panels).  Measured at N = 4096 (fused with the partial sums of top(k) beside D(k) / unfused): B = 16: 11.2 / 11.1 ms,
+// B = 24: 13.3 / 13.9, B = 32: 15.9 / 16.9, B = 48: 21.4 / 23.2, B = 64: 27.2 / 29.5.
+#define SF_UNFUSED_BELOW 20
 int sf_potrf_front_pad(int n, int batch) {
     static const bool off = SF_TUNE_FLAG("SF_NO_FRONT_PAD");  // tuning aid: A/B of the shifted frame
     static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");
     const int sel = g_chol_sequence.load();
-    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < 28);  // (as in sf_launch_potrf)
+    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < SF_UNFUSED_BELOW);  // (as in sf_launch_potrf)
     if (off || v1 || n % GT != 64 || n < 2 * GT) return 0;
     return 64;
 }
 
 int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
                     double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex) {
-    // The fused panel kernel (128-column panels) is the faster sequence once the batch fills the chip; small batches
-    // are bound by the number of sequential long-K steps, and the unfused sequence has half as many (256-column
-    // panels): measured at N = 4096, B = 16: 10.3 vs 11.2 ms; B = 24: 13.3 vs 13.7; B = 32: 16.6 vs 16.3; B = 64: 29.5 vs 28.3;
-    // B = 128: 55.3 vs 50.4.
+    // The fused panel kernel (128-column panels) is the faster sequence once the batch fills the chip (SF_UNFUSED_BELOW).
     static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");  // tuning aid: "1" always unfused, "0" always fused
     const int sel = g_chol_sequence.load();                 // sf_debug_cholesky_sequence(): tests drive both
-    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < 28);
+    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < SF_UNFUSED_BELOW);
     // The wide sequence (panel pairs, one 16-wave workgroup per CU) halves the A-operand stream and a third of all HBM
     // traffic of the factorisation; the chip is power-bound at full batches, so the clock it sustains rises by ~4 % --
     // but one workgroup per CU has nothing to overlap its epilogue and barriers with.  Measured (bench.py, same box):

@@ -16,7 +16,7 @@ for cfg, batches in plans:
     for B in batches:
         steps = "3" if cfg == "cfg5" else "10"
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--batch", str(B), "--steps", steps,
-                            "--warmup", "2", "--cpu-sample", "0", "--no-structured"], capture_output=True, text=True)
+                            "--warmup", "2", "--cpu-sample", "0", "--no-structured", "--no-extra-legs"], capture_output=True, text=True)
         d = json.loads(r.stdout.strip().splitlines()[-1])
         rows.append(dict(batch=B, ranks_equivalent=batches[0] // B, evals_per_s=d["value"], ms_per_step=d["ms_per_step"],
                          ms_per_eval=d["ms_per_step"] / B, panel_frac_of_peak=d["roofline"]["frac"]))
