@@ -329,7 +329,7 @@ int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, const doubl
  * (128-column panels, two workgroups per CU; the default once the batch fills the chip), the unfused one (256-column
  * panels, separate panel-solve and diagonal-update launches; fewer sequential steps, taken for batches below 20
  * matrices) and the wide one (pairs of panels, one 16-wave workgroup per CU keeps a 128 x 256 tile: a third less HBM
- * traffic; taken for batches of 96 or more matrices of 2048 or more rows).
+ * traffic; taken when batch x 128-row slabs >= 3400 and the matrices have 2048 or more rows).
  * mode -1 = choose by batch and matrix size (default), 0 = always fused, 1 = always unfused, 2 = always wide,
  * 3 = wide for the first half of the panels, then fused (test aid: exercises the hand-over between the two).
  * The fused and wide sequences factorise matrices of 64 mod 128 rows in a frame shifted by 64 virtual identity rows

@@ -2857,11 +2857,11 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     const int sel = g_chol_sequence.load();                 // sf_debug_cholesky_sequence(): tests drive both
     const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < SF_UNFUSED_BELOW);
     // The wide sequence (panel pairs, one 16-wave workgroup per CU) halves the A-operand stream and a third of all HBM
-    // traffic of the factorisation; the chip is power-bound at full batches, so the clock it sustains rises by ~4 % --
-    // but one workgroup per CU has nothing to overlap its epilogue and barriers with.  Measured (bench.py, same box):
-    // cfg 2 (N = 4096, B = 128) 0.5-1 % faster, cfg 3 (1600 units of N = 3008) equal, cfg 5 (N = 16384, B = 32) 2.4 %
-    // slower, B <= 64 slower -> taken only for full batches of mid-size matrices.
-    const bool wide_auto = batch >= 96 && n >= 2048;
+    // traffic of the factorisation, but one workgroup per CU has nothing to overlap its epilogue and barriers with: it pays
+    // once its launches are many rounds of workgroups.  Measured (bench.py, same box, fused / wide): N = 4096: B = 48
+    // 21.45 / 23.1 ms, 64: 27.34 / 27.4, 80: 33.0 / 33.4, 96: 38.2 / 38.6, 112: 44.6 / 43.9, 128: 49.7 / 48.4; N = 16384,
+    // B = 32 (cfg 5): 707.7 / 696.6; 1600 units of N = 3008 (cfg 3): 277.3 / 273.2 -> taken from batch x slabs >= 3400.
+    const bool wide_auto = n >= 2048 && (long long)batch * ((n + GT - 1) / GT) >= 3400;
     const bool v3 = sel >= 0 ? sel == 2 : (force ? force[0] == '2' : wide_auto);
     if (!ex) ex = sf_exec_thread_local();
     static const int tail_env = SF_TUNE_INT("SF_WIDE_TAIL_ROUNDS", -1);  // measured at cfg 2: -1 (wide to the end) 49.3 ms, 2: 50.0, 5: 50.4, 8: 51.0, 12: 51.8 (narrow: 51.5)
