@@ -915,12 +915,16 @@ __global__ __launch_bounds__(NT) void k_diag_mfma(double* __restrict__ T, int64_
 
 
 // The same diagonal-block step for the 128-column panels of the fused sequence, with the tile and its growing inverse
-// RESIDENT IN LDS (36 + 36 blocks of 16 x 17 doubles: 157 KB): k_diag_mfma keeps them in the L2-backed scratch, so
-// every one of its 8 block columns pays two global round trips (stage L(k,:), write X / read it back as an operand
-// of the next column), 55-65 us per tile when the chip is idle and three times that beside the panel launches.
-// Here the tile is read once, the eight columns run out of LDS (no staging buffers: an accumulator block is written
-// to its own destination block and read back in operand layout by the same wave), and L / L^-1 / z are written once.
-// One workgroup owns a CU while it runs (LDS), for a fraction of the time the old kernel held a slot.
+// RESIDENT IN LDS: k_diag_mfma keeps them in the L2-backed scratch, so every one of its 8 block columns pays two global
+// round trips (stage L(k,:), write X / read it back as an operand of the next column), 55-65 us per tile when the chip
+// is idle and three times that beside the panel launches.  Here the tile is read once, the eight columns run out of LDS
+// (no staging buffers: an accumulator block is written to its own destination block and read back in operand layout
+// by the same wave), and L / L^-1 / z are written once.
+// The inverse grows IN PLACE of the factor (36 blocks of 16 x 17 doubles + one: 79.6 KB, two workgroups per CU or one
+// beside a panel workgroup; with a second set of blocks for the inverse it was 157 KB = a whole CU): block column k of
+// W = L^-T is row k of L^-1, and row k of L is read for the last time at step k -- by the waves that update block column
+// k and by the waves that accumulate row k of the inverse, all before that step's first barrier -- so after it the
+// inverse waves drop X(e, k) into the slot of L(k, e).  L leaves for global memory block by block as it becomes final.
 __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, int64_t sT, int pw, int* __restrict__ info,
                                                   int info_off, double* __restrict__ rhs, int ldr,
                                                   double* __restrict__ Cdiag, int ldc, int64_t sC,
@@ -929,8 +933,8 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
     // the matrix there: never stored, read as zero) -- the first tile of a shifted frame, see sf_potrf_front_pad
     extern __shared__ double dsm[];
     double* Tl = dsm;              // lower blocks (bi >= bj) of the tile at (bi (bi + 1) / 2 + bj) * DBS
-    double* El = Tl + 36 * DBS;    // blocks X(e, j), e <= j, of W = L_kk^-T at (j (j + 1) / 2 + e) * DBS
-    double* Fb = El + 36 * DBS;    // inverse of the current 16 x 16 diagonal factor
+    double* El = Tl;               // blocks X(e, j), e <= j, of W = L_kk^-T: in the slot of L(j, e) once row j of L is dead
+    double* Fb = Tl + 36 * DBS;    // inverse of the current 16 x 16 diagonal factor
     double* rz = Fb + DBS;         // [128]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -940,7 +944,7 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
     double* Cb = Cdiag + (int64_t)b * sC;
     double* Wb = Wt + (int64_t)b * sW;
     auto tb = [](int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * DBS; };
-    auto eb = [](int e, int j) { return (j * (j + 1) / 2 + e) * DBS; };
+    auto eb = [](int e, int j) { return (j * (j + 1) / 2 + e) * DBS; };  // = tb(j, e)
 
     for (int idx = tid; idx < nb * nb * 256; idx += 512) {
         const int blk = idx >> 8, bi = blk / nb, bj = blk - bi * nb, r = (idx >> 4) & 15, c = idx & 15;
@@ -1004,13 +1008,14 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
             }
             const unsigned long long neg = __ballot(lane < 16 && !(pkeep > 0.0));
             if (neg && !bad) bad = 16 * k + __ffsll((long long)neg);
-            double* Ekk = El + eb(k, k);
+            double* Ekk = El + eb(k, k);  // (= own: the diagonal block of the tile has been consumed)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = lq + 4 * r;
                 Fb[row * DLD + l15] = f[r];
                 Ekk[l15 * DLD + row] = f[r];                      // X of the identity row block k is F^T
-                if (l15 >= row) own[l15 * DLD + row] = lt[r];     // L[i][j], lower triangle of the diagonal block
+                // L[i][j], lower triangle of the diagonal block: straight to the matrix
+                if (l15 >= row && 16 * k + row >= fp0) Cb[(int64_t)(16 * k + l15) * ldc + 16 * k + row] = lt[r];
             }
         }
         __syncthreads();
@@ -1029,15 +1034,17 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
             for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], f4[kk], x, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) own[(lq + 4 * r) * DLD + l15] = x[r];
+            if (isM && 16 * k + l15 >= fp0) {  // block (k + t, k) of L is final
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cb[(int64_t)(16 * ib + lq + 4 * r) * ldc + 16 * k + l15] = x[r];
+            }
         }
         __syncthreads();
     }
     if (tid == 0 && bad && info && info[b] == 0) info[b] = info_off + bad;
-    // ---- L -> matrix (lower triangle), Wt[c][j] = (L_kk^-1)[c][j] (block (cb, jb) = X(jb, cb)^T, zero above)
+    // ---- Wt[c][j] = (L_kk^-1)[c][j] (block (cb, jb) = X(jb, cb)^T, zero above)
     for (int idx = tid; idx < nb * nb * 256; idx += 512) {
         const int blk = idx >> 8, bi = blk / nb, bj = blk - bi * nb, r = (idx >> 4) & 15, c = idx & 15;
-        if ((bj < bi || (bj == bi && c <= r)) && 16 * bj + c >= fp0)
-            Cb[(int64_t)(16 * bi + r) * ldc + 16 * bj + c] = Tl[tb(bi, bj) + r * DLD + c];
         Wb[(int64_t)(16 * bi + r) * SF_LDT + 16 * bj + c] = bj <= bi ? El[eb(bj, bi) + c * DLD + r] : 0.0;
     }
     // ---- z_k = L_kk^-1 r_k with the explicit inverse
@@ -1053,7 +1060,7 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
         }
     }
 }
-#define SF_DIAG_LDS_BYTES ((73 * DBS + 128) * sizeof(double))
+#define SF_DIAG_LDS_BYTES ((37 * DBS + 128) * sizeof(double))
 static int sf_launch_diag128(double* T, int64_t sT, int pw, int* info, int info_off, double* rhs, int ldr, double* Cdiag,
                              int ldc, int64_t sC, double* Wt, int64_t sW, int batch, hipStream_t s, int fp0 = 0) {
     static const bool scratch = SF_TUNE_FLAG("SF_DIAG_SCRATCH");  // tuning aid: the L2-resident k_diag_mfma<512>
