@@ -652,8 +652,9 @@ def main():
             "whole_path_tflops": t["value"] * w.flops_eval / 1e12,
             "whole_path_frac_of_mfma_peak": t["value"] * w.flops_eval / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
             "roofline": {
-                "kernel": "k_chol_panel (fused v_mfma_f64_16x16x4_f64 panel step of the batched Cholesky: long-K update "
-                "+ triangular solve + diagonal-tile update)",
+                "kernel": "k_chol_panel_w / k_chol_panel (fused v_mfma_f64_16x16x4_f64 panel steps of the batched Cholesky: "
+                "long-K update + triangular solves + diagonal-tile update; panel pairs when batch x slabs >= 3400, "
+                "128-column panels for the chain and smaller batches)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
