@@ -2033,7 +2033,11 @@ static size_t sf_split_region_tiles(void) { return 2 * SF_CHIP_WGS; }  // partia
 static int sf_split_policy(long long wgs, int nk) {
     static const int force = SF_TUNE_INT("SF_CHOL_SPLIT", -1);  // tuning aid
     int S = 1;
-    while (2 * S <= SF_SPLIT_MAX && wgs * 2 * S <= SF_CHIP_WGS && nk / (2 * S) >= 8) S *= 2;
+    // (a split launch stops at 384 of the 512 slots: two slab groups are in flight and the chain's launches need room --
+    // N = 4096, cap 512 / 384 / 256 / 192: B = 16 11.22 / 11.18 / 11.26 / 11.71 ms, 32: 16.06 / 15.78 / 16.09 / 17.28,
+    // 64: 27.42 / 27.05 / 26.89 / 28.7)
+    static const int cap = SF_TUNE_INT("SF_SPLIT_CAP", 384);
+    while (2 * S <= SF_SPLIT_MAX && wgs * 2 * S <= cap && nk / (2 * S) >= 8) S *= 2;
     if (force >= 1) {
         S = 1;
         while (2 * S <= force && 2 * S <= SF_SPLIT_MAX && wgs * 2 * S <= 2 * SF_CHIP_WGS && nk / (2 * S) >= 8) S *= 2;
