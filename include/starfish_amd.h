@@ -327,7 +327,7 @@ int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, const doubl
 
 /* Tuning / test aid (process-global): the batched Cholesky has three launch sequences -- the fused panel kernel
  * (128-column panels, two workgroups per CU; the default once the batch fills the chip), the unfused one (256-column
- * panels, separate panel-solve and diagonal-update launches; fewer sequential steps, taken for batches below 20
+ * panels, separate panel-solve and diagonal-update launches; fewer sequential steps, taken for batches below 16
  * matrices) and the wide one (pairs of panels, one 16-wave workgroup per CU keeps a 128 x 256 tile: a third less HBM
  * traffic; taken when batch x 128-row slabs >= 3400 and the matrices have 2048 or more rows).
  * mode -1 = choose by batch and matrix size (default), 0 = always fused, 1 = always unfused, 2 = always wide,

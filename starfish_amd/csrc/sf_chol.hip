@@ -928,10 +928,11 @@ __global__ __launch_bounds__(NT) void k_diag_mfma(double* __restrict__ T, int64_
 __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, int64_t sT, int pw, int* __restrict__ info,
                                                   int info_off, double* __restrict__ rhs, int ldr,
                                                   double* __restrict__ Cdiag, int ldc, int64_t sC,
-                                                  double* __restrict__ Wt, int64_t sW, int fp0) {
+                                                  double* __restrict__ Wt, int64_t sW, int fp0, int prio) {
     // fp0: the first fp0 rows / columns of the tile are virtual (identity in T; Cdiag and rhs point fp0 elements BEFORE
     // the matrix there: never stored, read as zero) -- the first tile of a shifted frame, see sf_potrf_front_pad
     extern __shared__ double dsm[];
+    if (prio) __builtin_amdgcn_s_setprio(2);
     double* Tl = dsm;              // lower blocks (bi >= bj) of the tile at (bi (bi + 1) / 2 + bj) * DBS
     double* El = Tl;               // blocks X(e, j), e <= j, of W = L_kk^-T: in the slot of L(j, e) once row j of L is dead
     double* Fb = Tl + 36 * DBS;    // inverse of the current 16 x 16 diagonal factor
@@ -1060,6 +1061,7 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
         }
     }
 }
+static const int chain_prio = SF_TUNE_INT("SF_CHAIN_PRIO", 1);  // tuning aid: 0 = the chain's workgroups at normal wave priority
 #define SF_DIAG_LDS_BYTES ((37 * DBS + 128) * sizeof(double))
 static int sf_launch_diag128(double* T, int64_t sT, int pw, int* info, int info_off, double* rhs, int ldr, double* Cdiag,
                              int ldc, int64_t sC, double* Wt, int64_t sW, int batch, hipStream_t s, int fp0 = 0) {
@@ -1073,7 +1075,7 @@ static int sf_launch_diag128(double* T, int64_t sT, int pw, int* info, int info_
             return SF_OK;
         }));
         hipLaunchKernelGGL(k_diag_lds, dim3(batch), dim3(512), SF_DIAG_LDS_BYTES, s, T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc,
-                           sC, Wt, sW, fp0);
+                           sC, Wt, sW, fp0, chain_prio);
     }
     SF_LAUNCH_CHECK();
     return SF_OK;
@@ -1128,6 +1130,7 @@ struct sf_panel_args {
     // row0 / the tile map count in that frame.  Rows and columns < fp are virtual (identity): every K loop starts at
     // column fp, the panel-0 accesses that would touch a virtual column are predicated.  0 for unshifted matrices.
     int fp;
+    int prio;  // wave priority (s_setprio) of the whole workgroup: the chain's launches share their SIMDs with bulk workgroups
 };
 
 // granule swizzle of the main loop's LDS image (see k_chol_panel)
@@ -1172,6 +1175,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
     const int rows_here = min(GT, ((g.nband && row0 < g.nband) ? g.nband : g.n) - row0);
     const int pw = g.pw, k0 = g.k0;
     const int cfp = k0 == 0 ? g.fp : 0;  // panel columns below cfp are virtual (zero below the diagonal tile)
+    if (g.prio) __builtin_amdgcn_s_setprio(2);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -2346,6 +2350,7 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
             g.Sout = T;
             g.sS = sT;
             g.ldS = SF_LDT;
+            g.prio = chain_prio;
         }
         g.fp = fp;
         if (gen) {
@@ -2534,6 +2539,7 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
             g.Sout = T;
             g.sS = sT;
             g.ldS = SF_LDT;
+            g.prio = chain_prio;
         }
         g.fp = fp;
         if (gen) {
@@ -2855,9 +2861,9 @@ int sf_launch_potrf_band(int n, int nband, int halfwidth, int batch, const doubl
 }
 
 // Small batches are bound by the number of sequential long-K steps; the unfused sequence has half as many (256-column
-// panels).  Measured at N = 4096 (fused with the partial sums of top(k) beside D(k) / unfused): B = 16: 11.2 / 11.1 ms,
-// B = 24: 13.3 / 13.9, B = 32: 15.9 / 16.9, B = 48: 21.4 / 23.2, B = 64: 27.2 / 29.5.
-#define SF_UNFUSED_BELOW 20
+// panels).  Measured at N = 4096, fused (partial sums of top(k) beside D(k), chain at raised wave priority) / unfused:
+// B = 12: 10.0 / 9.05-9.6 ms, 16: 10.97 / 11.1, 20: 12.2 / 12.6, 24: 13.3 / 13.9, 32: 15.4 / 16.9, 64: 26.1 / 29.5.
+#define SF_UNFUSED_BELOW 16
 int sf_potrf_front_pad(int n, int batch) {
     static const bool off = SF_TUNE_FLAG("SF_NO_FRONT_PAD");  // tuning aid: A/B of the shifted frame
     static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");
