@@ -355,14 +355,99 @@ def short_summary(w, t):
     }
 
 
+def code_id():
+    """sha1 (16 hex digits) over the sources that determine what is measured: the HIP / C-ABI sources and this file.
+    tools/summarize_profile.py stamps the same id into the PMC summaries, so `roofline.traffic` can say whether the
+    counters were collected on THIS code (the snapshot on the GPU box has no .git)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "starfish_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "starfish_amd", "csrc", "*.cpp"))
+                   + glob.glob(os.path.join(ROOT, "starfish_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "starfish_amd.h")])
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def fill_leg(w, steps=5, warmup=2):
+    """the fill stage alone is HBM-WRITE bound.  sf_cov_fill_batch, full dense matrices (both triangles,
+    sigma^2 + K_global + K_local + rank-m term on MFMA + jitter), row stride N: 8 N^2 B algorithmic bytes per launch, all
+    written, nothing read back.  Timed with HIP events around the fill launches on their stream (the library's profile
+    scopes: the transform chain that precedes the fill is a separate scope).  Next to it the plain streaming write of
+    the same array (sf_debug_stream_write): the write rate this box sustains."""
+    import torch
+
+    from starfish_amd import _device as D
+
+    dev, md, lib, B, N = w.dev, w.md, w.lib, w.n_local, w.N
+    cov = torch.empty((B, N, N), dtype=torch.float64, device=dev.dev)
+    info = D.empty((B,), dev.dev, torch.int32)
+    nbytes = 8.0 * N * N * B
+    for _ in range(warmup):
+        dev.cov_fill_device(md, w.P_dev, cov, N, N * N, lower_only=False, add_jitter=True, info=info)
+    torch.cuda.synchronize()
+    lib.sf_profile_read(None, None, None, None)
+    lib.sf_profile_enable(1)
+    for _ in range(steps):
+        dev.cov_fill_device(md, w.P_dev, cov, N, N * N, lower_only=False, add_jitter=True, info=info)
+    torch.cuda.synchronize()
+    lib.sf_profile_enable(0)
+    ms = (C.c_double * 6)()
+    lib.sf_profile_read(ms, None, None, None)
+    assert (info.cpu().numpy() == 0).all()
+    fill_ms = ms[1] / steps
+    # streaming-write probe over the same array
+    s = D.stream_ptr(dev.dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        lib.sf_debug_stream_write(D.ptr(cov), cov.numel(), 0.0, s)
+    e0.record()
+    for _ in range(steps):
+        lib.sf_debug_stream_write(D.ptr(cov), cov.numel(), 0.0, s)
+    e1.record()
+    torch.cuda.synchronize()
+    write_ms = e0.elapsed_time(e1) / steps
+    del cov
+    torch.cuda.empty_cache()
+    gbs = nbytes / (fill_ms * 1e-3) / 1e9
+    probe = nbytes / (write_ms * 1e-3) / 1e9
+    traffic, src, same = pmc_lookup("fill", "k_fill_tiles")
+    return {
+        "kernel": "k_fill_tiles<true> via sf_cov_fill_batch: full dense C (both triangles, jitter on), row stride N",
+        "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+        "stream_write_probe_gbs": probe, "frac_of_stream_write_probe": gbs / probe if probe > 0 else None,
+        "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": fill_ms, "transforms_ms_before_it": ms[0] / steps,
+        "launches": steps, "traffic": traffic, "traffic_source": src, "traffic_is_this_code": same,
+        "note": "write-only pass: algorithmic bytes = 8 N^2 B; matrices per second = 1e3 B / avg_launch_ms",
+        "matrices_per_s": B / (fill_ms * 1e-3),
+    }
+
+
+def pmc_lookup(tag, kernel_key):
+    """(hbm bytes per launch, source file, collected-on-this-code?) of the latest profiles/r0?_*<tag>*_pmc_summary.json."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0[0-9]_*{tag}*_pmc_summary.json")))[-1:]:
+        with open(f) as fh:
+            summ = json.load(fh)
+        for key, val in summ.items():
+            if isinstance(val, dict) and key.lstrip("_").startswith(kernel_key) and "hbm_bytes_per_launch" in val:
+                cid = summ.get("_code_id")
+                return val["hbm_bytes_per_launch"], os.path.relpath(f, ROOT) + (f" @code {cid}" if cid else ""), (cid == code_id()) if cid else None
+    return None, None, None
+
+
 class Comm:
     """Barrier + max-over-ranks of a scalar: the only things the process group is used for."""
 
-    def __init__(self, dist, device):
-        self.dist, self.device = dist, device
+    def __init__(self, dist, device, group=None, dev_index=None):
+        self.dist, self.device, self.group, self.dev_index = dist, device, group, dev_index
 
     def barrier(self):
-        if self.dist is not None:
+        if self.dist is None:
+            return
+        if self.group is not None:  # nccl / RCCL group: the barrier is an all-reduce on this rank's own device
+            self.dist.barrier(group=self.group, device_ids=[self.dev_index])
+        else:
             self.dist.barrier()
 
     def max(self, x):
@@ -371,8 +456,130 @@ class Comm:
         import torch
 
         t = torch.tensor([x], dtype=torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)  # timing only: the data path has no collective
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)  # timing only: the data path has no collective
         return float(t.item())
+
+
+def make_process_group(world, dev_index, share):
+    """(dist, Comm, note).  The default group is gloo (rendezvous on MASTER_ADDR, carries the agreement below and is
+    the fallback); the barrier / timing-max group is nccl == RCCL over xGMI, created on top of it and tried with one
+    all-reduce.  If RCCL cannot be brought up on ANY rank (agreed with a MIN over gloo) every rank falls back to gloo and
+    the JSON line says so in `process_group` -- the data path has no collective either way."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+    assert dist.get_world_size() == world
+    cpu = torch.device("cpu")
+    if share:  # test hook: RCCL refuses two ranks on one device
+        return dist, Comm(dist, cpu), "gloo (test hook: ranks share device 0)"
+    ok, why, grp = 1, "", None
+    cuda = torch.device("cuda", dev_index)
+    try:
+        if os.environ.get("SF_BENCH_FAIL_NCCL") == "1":  # test hook: exercise the fallback
+            raise RuntimeError("SF_BENCH_FAIL_NCCL=1")
+        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300), device_id=cuda)
+        t = torch.ones(1, dtype=torch.float64, device=cuda)
+        dist.all_reduce(t, group=grp)
+        torch.cuda.synchronize()
+        assert int(t.item()) == world, t.item()
+    except Exception as e:  # noqa: BLE001 -- whatever RCCL raises: report it, do not die
+        ok, why = 0, f"{type(e).__name__}: {str(e).splitlines()[0][:200] if str(e) else ''}"
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return dist, Comm(dist, cuda, grp, dev_index), "nccl (RCCL)"
+    sys.stderr.write(f"bench.py: rank {os.environ.get('RANK')}: RCCL group unavailable ({why or 'another rank failed'}); using gloo\n")
+    return dist, Comm(dist, cpu), "gloo (fallback: the nccl/RCCL group could not be created" + (f": {why}" if why else " on another rank") + ")"
+
+
+class ErrorLine:
+    """Whatever happens, rank 0 prints ONE parsable JSON line.  An exception on rank 0 prints {"error": ...}; a failure
+    elsewhere makes the launcher SIGTERM the surviving ranks -- rank 0 may be blocked inside a collective then, where a
+    Python signal handler would never run, so the signal's wake-up byte is read by a watchdog THREAD which prints the
+    line (with what the failed ranks left in their error files) and exits."""
+
+    def __init__(self, args, rank, world):
+        import signal
+        import tempfile
+        import threading
+
+        self.args, self.rank, self.world, self.printed = args, rank, world, False
+        self.lock = threading.Lock()
+        tag = os.environ.get("MASTER_PORT") or str(os.getppid())
+        self.dir = os.path.join(tempfile.gettempdir(), f"sf_bench_errors_{tag}")
+        if world > 1 and rank == 0:
+            try:
+                os.makedirs(self.dir, exist_ok=True)
+                for f in glob.glob(os.path.join(self.dir, "rank*.err")):
+                    os.remove(f)
+                self.rd, wr = socket.socketpair()
+                wr.setblocking(False)
+                signal.signal(signal.SIGTERM, lambda *a: None)
+                signal.set_wakeup_fd(wr.fileno(), warn_on_full_buffer=False)
+                self._wr = wr
+                threading.Thread(target=self._watch, daemon=True).start()
+            except Exception:  # pragma: no cover -- never let the safety net break the bench
+                pass
+
+    def _watch(self):
+        import signal
+
+        while True:
+            b = self.rd.recv(16)
+            if not b:
+                return
+            if signal.SIGTERM in b:
+                time.sleep(0.5)  # let the failing rank finish writing its error file
+                self.emit("terminated by the launcher (SIGTERM): another rank failed" + self._others())
+                os._exit(143)
+
+    def _others(self):
+        out = []
+        for f in sorted(glob.glob(os.path.join(self.dir, "rank*.err"))):
+            try:
+                with open(f) as fh:
+                    out.append(f"{os.path.basename(f)[:-4]}: {fh.read().strip()[:400]}")
+            except OSError:
+                pass
+        return (" -- " + " | ".join(out)) if out else ""
+
+    def emit(self, msg):
+        with self.lock:
+            if self.printed or self.rank != 0:
+                return
+            self.printed = True
+            cfg = CONFIGS[self.args.config]
+            print(json.dumps({
+                "metric": f"log-likelihood evals/sec, {self.args.npix or cfg['npix']}-pixel order, batch={self.args.batch or cfg['batch']} walkers",
+                "value": None, "unit": "evals/s", "n_gpus": self.world, "steps": self.args.steps, "warmup": self.args.warmup,
+                "ms_per_step": None, "higher_is_better": True, "scaling": self.args.scaling, "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic", "config": {"workload": cfg["label"]}, "error": msg,
+            }), flush=True)
+
+    def result(self, out):
+        with self.lock:
+            if not self.printed:
+                self.printed = True
+                print(json.dumps(out), flush=True)
+
+    def failed(self, exc):
+        import traceback
+
+        msg = f"rank {self.rank}: {type(exc).__name__}: {exc}"
+        sys.stderr.write(traceback.format_exc())
+        if self.rank == 0:
+            self.emit(msg)
+        else:
+            try:
+                os.makedirs(self.dir, exist_ok=True)
+                with open(os.path.join(self.dir, f"rank{self.rank}.err"), "w") as fh:
+                    fh.write(msg)
+            except OSError:
+                pass
 
 
 def structured_leg(w, args, comm, lnl_host, custom):
@@ -487,6 +694,8 @@ def main():
     ap.add_argument("--cpu-pool-evals", type=int, default=3, help="cpu_baseline pool: timed evaluations per process")
     ap.add_argument("--no-structured", action="store_true", help="skip the banded-solver secondary figure")
     ap.add_argument("--no-cpu-pool", action="store_true", help="cpu_baseline: single-process mode only")
+    ap.add_argument("--fill-only", action="store_true",
+                    help="run only the HBM-write leg (sf_cov_fill_batch, full dense) and print its object: for rocprofv3 passes")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip other_configs (cfg 3 / cfg 5) and strong_scaling_proxy of the default run")
     args = ap.parse_args()
@@ -497,15 +706,27 @@ def main():
     if args.gpus > 1 and not in_group:
         launch_ranks(args.gpus, sys.argv[1:])  # does not return
 
-    import numpy as np
-    import torch
-
     rank = int(os.environ.get("RANK", "0")) if in_group else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if in_group else 0
     world = int(os.environ.get("WORLD_SIZE", "1")) if in_group else 1
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)\n")
         sys.exit(2)
+    line = ErrorLine(args, rank, world)
+    try:
+        run(args, in_group, rank, local_rank, world, line)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 -- rank 0 still prints one parsable line; the launcher sees a failure
+        line.failed(e)
+        sys.stdout.flush()
+        os._exit(1)  # (not sys.exit: a wedged process group must not keep the interpreter in its destructors)
+
+
+def run(args, in_group, rank, local_rank, world, line):
+    import numpy as np
+    import torch
+
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
     share = os.environ.get(SHARE_GPU_ENV) == "1"
     ndev = torch.cuda.device_count()
@@ -514,7 +735,11 @@ def main():
         sys.exit(2)
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
-    use_dist = world > 1
+    # (SF_BENCH_FORCE_GROUP=1: take the process-group branch with ONE rank too -- RCCL accepts a single rank; the -m gpu
+    # test uses it to run init, barrier, all-reduce and the clock-probe order of the N > 1 path on the one-GPU box)
+    use_dist = world > 1 or (in_group and os.environ.get("SF_BENCH_FORCE_GROUP") == "1")
+    if os.environ.get("SF_BENCH_FAIL_RANK") == str(rank):  # test hook: this rank dies before the process group exists
+        raise RuntimeError("SF_BENCH_FAIL_RANK test hook")
 
     cfg = dict(CONFIGS[args.config])
     custom = []
@@ -534,8 +759,6 @@ def main():
     clock_mhz = None
     dist = None
     if use_dist:
-        import torch.distributed as dist
-
         # With RCCL initialised the spinning probe kernel serialises with the main stream (measured: +40 ms on the
         # timed region), so under a process group the sustained clock is sampled BEFORE the group is created, over
         # untimed steps of the same workload on this rank's GPU.
@@ -544,14 +767,14 @@ def main():
             clock_mhz = pre["clock_mhz"]
             clock_note = "sampled on rank 0 over 2 untimed steps of the same workload before the process group was created"
             clock = None
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if share:
-            dist.init_process_group("gloo")  # test hook: RCCL refuses two ranks on one device
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        assert dist.get_world_size() == world
-    comm = Comm(dist, torch.device("cpu") if share else device)
+        dist, comm, pg_note = make_process_group(world, dev_index, share)
+    else:
+        comm, pg_note = Comm(None, device), None
 
+    if args.fill_only:
+        assert n_orders == 1 and not use_dist, "--fill-only: single-order configs on one GPU"
+        print(json.dumps({"fill": fill_leg(w, steps=args.steps, warmup=args.warmup)}), flush=True)
+        return
     t = timed_leg(w, args.steps, args.warmup, args.profile_steps, comm, clock if not use_dist else None)
     if not use_dist:
         clock_mhz = t["clock_mhz"]
@@ -574,10 +797,11 @@ def main():
         w2.release()
     default_run = (world == 1 and args.config == "cfg2" and not custom and args.grid == "loguniform"
                    and not args.no_extra_legs)
-    extra, proxy = None, None
+    extra, proxy, fill = None, None, None
     if default_run:
         plist0, order0 = w.plist, w.order0
         base_ms_per_eval = t["ms_per_step"] / w.n_local
+        fill = fill_leg(w)
         w.release()
         # strong-scaling proxy on the one GPU: the per-rank batch of 2 / 4 / 8 ranks (128/G walkers)
         proxy = [{"ranks_equivalent": 1, "batch": B, "value": t["value"], "ms_per_step": t["ms_per_step"],
@@ -605,15 +829,9 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 as the
         # micro-arch guide prescribes for gfx950, + WRITE_SIZE) summarised under profiles/ by
         # tools/summarize_profile.py; bench.py cannot collect counters itself.
-        traffic, traffic_src = None, None
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0[0-9]_*{args.config}*_pmc_summary.json")))[-1:]:
-            if not custom and args.grid == "loguniform":
-                with open(f) as fh:
-                    summ = json.load(fh)
-                key = "_k_chol_panel_all" if "_k_chol_panel_all" in summ else None
-                if key:
-                    traffic = summ[key]["hbm_bytes_per_launch"]
-                    traffic_src = os.path.relpath(f, ROOT)
+        traffic, traffic_src, traffic_same = (None, None, None)
+        if not custom and args.grid == "loguniform":
+            traffic, traffic_src, traffic_same = pmc_lookup(args.config, "k_chol_panel_all")
         ms, prof_steps, achieved = t["ms"], t["prof_steps"], t["achieved"]
         label = cfg["label"] + (" [custom: " + ", ".join(custom) + "]" if custom else "")
         per = " per GPU" if args.scaling == "weak" else " in total"
@@ -646,9 +864,9 @@ def main():
                 "global_batch": w.units_total,
                 "units_per_gpu": w.n_local,
                 "parallelism": f"(order x walker) units sharded x{world}, one process per GPU, no data-path collective"
-                + (" (process group: " + ("gloo, ranks share device 0 [test hook]" if share else "nccl/RCCL") + ", barrier + timing max only)"
-                   if use_dist else ""),
+                + (f" (process group: {pg_note}, barrier + timing max only)" if use_dist else ""),
             },
+            "process_group": pg_note,
             "whole_path_tflops": t["value"] * w.flops_eval / 1e12,
             "whole_path_frac_of_mfma_peak": t["value"] * w.flops_eval / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
             "roofline": {
@@ -665,6 +883,8 @@ def main():
                 "peak_at_sustained_clock": FP64_MFMA_PEAK_TFLOPS * clock_mhz / 2400.0 if clock_mhz else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_is_this_code": traffic_same,
+                "code_id": code_id(),
                 "note": "rank 0's GPU; the panel launches run on several streams (lookahead chain, slab groups) and overlap: "
                 "`achieved` divides by the UNION of the launch intervals (HIP events, common origin, recorded during the last "
                 "`profiled_steps` of the timed steps); avg_launch_ms is the plain mean launch duration (what rocprofv3 "
@@ -682,6 +902,16 @@ def main():
             "potrf_stage_tflops": w.n_local * prof_steps * (N**3 / 3) / (ms[3] * 1e-3) / 1e12 if ms[3] > 0 else None,
             "structured_solver": structured,
         }
+        if fill is not None:
+            out["roofline"]["fill"] = fill  # "the fill stage alone is HBM-write-bound ... report both"
+        if extra is not None:  # scalars of the secondary legs inside `roofline` (the driver keeps this object)
+            out["roofline"]["cfg3_frac"] = extra["cfg3"]["roofline"]["frac"]
+            out["roofline"]["cfg5_frac"] = extra["cfg5"]["roofline"]["frac"]
+            out["roofline"]["cfg3_whole_path_frac"] = extra["cfg3"]["whole_path_frac_of_mfma_peak"]
+            out["roofline"]["cfg5_whole_path_frac"] = extra["cfg5"]["whole_path_frac_of_mfma_peak"]
+        if proxy is not None:
+            for row in proxy[1:]:
+                out["roofline"][f"b{row['batch']}_efficiency"] = row["per_eval_efficiency_vs_full_batch"]
         if other is not None:
             out[other_mode] = other
         if proxy is not None:
@@ -692,9 +922,9 @@ def main():
             out["other_configs"] = extra
         if world == 1 and args.cpu_sample > 0 and plist0:
             out["cpu_baseline"] = cpu_baseline(order0, plist0, lnl_host, args)
-        print(json.dumps(out), flush=True)
+        line.result(out)
     if use_dist:
-        dist.barrier()
+        comm.barrier()
         dist.destroy_process_group()
 
 

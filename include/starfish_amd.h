@@ -341,6 +341,10 @@ int sf_debug_cholesky_sequence(int mode);
  * writes {shader-clock ticks, wall ticks} to d_out2[2] -> sustained shader clock under load. */
 int sf_debug_clock_probe(long long* d_out2, long long wall_ticks_100mhz, void* stream);
 
+/* Measurement aid (bench.py's fill leg): a plain streaming write of `count` doubles (16-byte stores, one pass, nothing
+ * read) -- the HBM write rate this box sustains, next to which the write-only covariance fill is priced. */
+int sf_debug_stream_write(double* d_dst, size_t count, double value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -507,15 +507,20 @@ class DeviceOrder:
                 info=info.cpu().numpy(),
             )
 
-    def cov_fill(self, md, params, ld=None, lower_only=False, add_jitter=False):
+    def cov_fill(self, md, params, ld=None, lower_only=False, add_jitter=False, guard=0):
         """The fused covariance fill alone (sf_cov_fill_batch): (B, n, ld) array, row stride ``ld`` >= n (columns
-        beyond n are left as allocated: zero here)."""
+        beyond n are left as allocated: zero here).  Exactly n rows per matrix are written -- no identity padding, that
+        belongs to the library's own workspace layout.  ``guard`` > 0 appends that many sentinel doubles (-7.0) behind the
+        last matrix and returns them as a third value (tests: nothing may be written past the caller's array)."""
         torch = _torch()
         with torch.cuda.device(self.dev):
             P = params if torch.is_tensor(params) else to_dev(params, self.dev)
             B = int(P.shape[0])
             ld = int(ld or self.n)
-            cov = torch.zeros((B, self.n, ld), dtype=torch.float64, device=self.dev)
+            buf = torch.zeros((B * self.n * ld + int(guard),), dtype=torch.float64, device=self.dev)
+            if guard:
+                buf[B * self.n * ld:] = -7.0
+            cov = buf[: B * self.n * ld].view(B, self.n, ld)
             info = empty((B,), self.dev, torch.int32)
             ws = self._work(md, B)
             rc = self.lib.sf_cov_fill_batch(
@@ -523,7 +528,21 @@ class DeviceOrder:
                 ptr(ws), ws.numel(), stream_ptr(self.dev),
             )
             _lib.check(rc, "sf_cov_fill_batch")
+            if guard:
+                return cov.cpu().numpy(), info.cpu().numpy(), buf[B * self.n * ld:].cpu().numpy()
             return cov.cpu().numpy(), info.cpu().numpy()
+
+    def cov_fill_device(self, md, P_dev, cov, ld, stride, lower_only=False, add_jitter=True, info=None):
+        """Enqueue-only sf_cov_fill_batch into a caller-held device array (bench.py's fill leg): no host copies."""
+        torch = _torch()
+        with torch.cuda.device(self.dev):
+            B = int(P_dev.shape[0])
+            ws = self._work(md, B)
+            rc = self.lib.sf_cov_fill_batch(
+                self.ctx, C.byref(md), B, ptr(P_dev), ptr(cov), int(ld), int(stride), int(lower_only), int(add_jitter),
+                ptr(info) if info is not None else C.c_void_p(0), ptr(ws), ws.numel(), stream_ptr(self.dev),
+            )
+            _lib.check(rc, "sf_cov_fill_batch")
 
     def transform(self, md, params):
         torch = _torch()

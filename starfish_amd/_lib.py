@@ -12,7 +12,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SF_LIB_PATH: development hook for tools/ -- load another build of the SAME library (the `make TUNING=1` variant with
 # the environment tuning switches compiled in).  The release library itself reads no environment variable.
-LIB_PATH = os.environ.get("SF_LIB_PATH") or os.path.join(_HERE, "libstarfish_amd.so")
+LIB_PATH = os.path.join(_HERE, "libstarfish_amd.so")
+if os.environ.get("SF_LIB_PATH"):
+    import warnings
+
+    LIB_PATH = os.environ["SF_LIB_PATH"]
+    warnings.warn(f"starfish_amd: SF_LIB_PATH overrides the packaged library: loading {LIB_PATH}", RuntimeWarning)
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -144,6 +149,7 @@ SIGNATURES = {
         [_VP, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _VP, C.c_int, C.c_int, C.c_int64, _VP, _VP, _VP, _VP],
     ),
     "sf_debug_clock_probe": (C.c_int, [_VP, C.c_longlong, _VP]),
+    "sf_debug_stream_write": (C.c_int, [_VP, C.c_size_t, C.c_double, _VP]),
     "sf_debug_cholesky_sequence": (C.c_int, [C.c_int]),
     "sf_profile_enable": (C.c_int, [C.c_int]),
     "sf_profile_read": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),

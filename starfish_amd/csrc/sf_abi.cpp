@@ -899,6 +899,7 @@ static sf_fill_args fill_args(sf_ctx* c, const sf_model_desc* mdl, const double*
     f.off_local = 6 + c->P + mdl->n_cheb;
     f.monotonic = c->monotonic;
     f.loguniform = c->loguniform;
+    f.nout = 0;
     f.tilemap = nullptr;
     f.nt128 = 0;
     f.fp = 0;
@@ -1003,17 +1004,25 @@ extern "C" int sf_cov_fill_batch(sf_ctx* c, const sf_model_desc* mdl, int B, con
     }
     hipStream_t s = (hipStream_t)stream;
     Work w = carve(c, mdl, B, d_work, work_bytes, false);
-    // (the rank-m term needs Y = L_w^-1 (Omega X): the transform chain and the emulator query run first)
-    rc = run_transforms(c, mdl, B, d_params, w, nullptr, nullptr, nullptr, nullptr, true, s);
-    if (rc) return rc;
-    sf_fill_args f = fill_args(c, mdl, d_params, w);
-    f.C = d_cov;
-    f.lda = ld;
-    f.stride = stride;
-    f.lower_only = lower_only ? 1 : 0;
-    f.add_jitter = add_jitter ? 1 : 0;
-    rc = sf_launch_fill(f, B, s);
-    if (rc) return rc;
+    prof_count_call();
+    {
+        // (the rank-m term needs Y = L_w^-1 (Omega X): the transform chain and the emulator query run first)
+        ProfScope ps(s, PS_TRANSFORM);
+        rc = run_transforms(c, mdl, B, d_params, w, nullptr, nullptr, nullptr, nullptr, true, s);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(s, PS_FILL);
+        sf_fill_args f = fill_args(c, mdl, d_params, w);
+        f.C = d_cov;
+        f.lda = ld;
+        f.stride = stride;
+        f.lower_only = lower_only ? 1 : 0;
+        f.add_jitter = add_jitter ? 1 : 0;
+        f.nout = c->n;  // the caller's matrices have n rows: no identity padding (it belongs to the workspace layout only)
+        rc = sf_launch_fill(f, B, s);
+        if (rc) return rc;
+    }
     if (d_info) SF_HIP(hipMemcpyAsync(d_info, w.info_e, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, s));
     return SF_OK;
 }
@@ -1678,6 +1687,14 @@ extern "C" int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, 
 extern "C" int sf_debug_cholesky_sequence(int mode) { return sf_set_cholesky_sequence(mode); }
 
 // Tuning aid (not part of the Starfish surface): sustained shader clock while other streams are busy.
+extern "C" int sf_debug_stream_write(double* d_dst, size_t count, double value, void* stream) {
+    if (!d_dst) {
+        sf_set_error("sf_debug_stream_write: d_dst is required");
+        return SF_EINVAL;
+    }
+    return sf_launch_stream_write(d_dst, count, value, (hipStream_t)stream);
+}
+
 extern "C" int sf_debug_clock_probe(long long* d_out2, long long wall_ticks_100mhz, void* stream) {
     return sf_launch_clock_probe(d_out2, wall_ticks_100mhz, (hipStream_t)stream);
 }

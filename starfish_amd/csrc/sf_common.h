@@ -80,6 +80,7 @@ static inline int sf_once_per_device(sf_dev_once* once, F&& setup) {
 #ifndef SF_EXEC_GROUPS
 #define SF_EXEC_GROUPS 2
 #endif
+static_assert(SF_EXEC_GROUPS >= 2, "the wide sequence and the multi-order lanes use grp[0]: at least two slab groups");
 // streams the slab groups of the fused Cholesky are spread over (the caller's + 1; measured: 1 -> 54.8, 2 -> 52.9, 3 -> 53.8 ms at cfg 2)
 struct sf_exec {
     int device = -1;
@@ -148,6 +149,8 @@ struct sf_fill_args {
     int has_global, n_local, off_global, off_local;
     int lower_only;        // 1: only tiles touching the lower triangle, identity padding written
     int add_jitter;        // 1: + SF_JITTER on the diagonal
+    int nout;              // rows / columns of C that are written; 0: npad with lower_only (workspace matrices: identity
+                           // padding included), n otherwise.  Caller-owned matrices of n rows set it to n
     int monotonic;         // wave sorted ascending -> band culling allowed
     int loguniform;        // wave_i = wave_0 e^(i delta) to rounding -> K_global depends on i-j only
     unsigned char* tilemap; // optional [B][nt128*nt128]: 1 = the 128x128 tile is materialised in C
@@ -161,7 +164,11 @@ struct sf_fill_args {
     int list_cap;
     double* gtab;          // optional [B][n] scratch: K_global per diagonal (log-uniform grids, likelihood path)
 };
+static inline __host__ __device__ int sf_fill_extent(const sf_fill_args& a) {
+    return a.nout > 0 ? a.nout : (a.lower_only ? a.npad : a.n);
+}
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);
+int sf_launch_stream_write(double* dst, size_t count, double v, hipStream_t s);
 // band storage of the structured part of C (sf_band.hip consumes it); a.npad = rows written (>= a.n)
 int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int halfwidth, int ldb, int64_t sband,
                         int* info, double* gtab, hipStream_t s, int tile_wt = -1);  // ws stored diagonals > halfwidth; gtab: B x (ws+1) or NULL

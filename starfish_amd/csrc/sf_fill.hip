@@ -107,7 +107,7 @@ __device__ __forceinline__ void sf_fill_tile(const sf_fill_args& a, int b, int t
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
-    const int nout = a.lower_only ? a.npad : a.n;  // extent of the stored matrix
+    const int nout = sf_fill_extent(a);  // extent of the stored matrix
     if (R0 >= nout || C0 >= nout) return;
     if (a.lower_only && C0 > R0 + 31) return;
     const int gam = lane & 15, q = lane >> 4;
@@ -177,7 +177,7 @@ __device__ __forceinline__ void sf_fill_tile(const sf_fill_args& a, int b, int t
     }
     const bool structured = do_glob || lmask;
 
-    const bool vec_ok = (a.lda & 1) == 0;
+    const bool vec_ok = ((a.lda | a.stride) & 1) == 0;  // 16-byte stores need even row and matrix strides
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
         const int row = R0 + ti * 16 + gam;
@@ -286,7 +286,7 @@ int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s) {
         sf_set_error("fill: a shifted tile frame needs fp = 64, a tile map and lower_only");
         return SF_EINVAL;
     }
-    const int nout = a.lower_only ? a.npad : a.n;
+    const int nout = sf_fill_extent(a);
     const int nt = (nout + FT - 1) / FT;
     const long long nblk = (long long)nt * nt * B;
     if (nblk > 0x7fffffffLL) {
@@ -500,6 +500,34 @@ int sf_launch_local_cov(const double* wave, int n, double amp, double mu, double
     if (n <= 0) return SF_OK;
     hipLaunchKernelGGL(k_local_cov, dim3((n + 255) / 256, n), dim3(256), 0, s, wave, n, amp, mu, sigma,
                        accumulate, out);
+    SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+
+// Streaming-write probe (sf_debug_stream_write): every lane stores 16 bytes per iteration, a workgroup covers a contiguous
+// 64 KB chunk per iteration (the write pattern of a bandwidth test, no reads).
+__global__ __launch_bounds__(256) void k_stream_write(double* __restrict__ dst, size_t count2, double v) {
+    double2* __restrict__ d2 = (double2*)dst;
+    const double2 val = make_double2(v, v);
+    const size_t chunk = 4096;  // double2 per workgroup and iteration
+    for (size_t base = (size_t)blockIdx.x * chunk; base < count2; base += (size_t)gridDim.x * chunk) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const size_t j = base + (size_t)i * 256 + threadIdx.x;
+            if (j < count2) d2[j] = val;
+        }
+    }
+}
+int sf_launch_stream_write(double* dst, size_t count, double v, hipStream_t s) {
+    if (((uintptr_t)dst & 15) != 0 || (count & 1)) {
+        sf_set_error("stream write probe: 16-byte aligned destination and an even count");
+        return SF_EINVAL;
+    }
+    const size_t count2 = count / 2;
+    if (!count2) return SF_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((count2 + 4095) / 4096, 256 * 32);
+    hipLaunchKernelGGL(k_stream_write, dim3(grid), dim3(256), 0, s, dst, count2, v);
     SF_LAUNCH_CHECK();
     return SF_OK;
 }

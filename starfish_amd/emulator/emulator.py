@@ -82,13 +82,24 @@ class Emulator:
         (:meth:`log_likelihood`), so a Nelder-Mead step does not pay the 17 ms numpy build of the 1320 x 1320 matrix
         of the worked example."""
         self._v11 = None
+        self._v11_key = None
         self._v11_assigned = False
         self._device = None  # the device-side factor of v11 is rebuilt lazily
         self._factor = None
 
+    def _hyper_key(self):
+        return tuple(float(v) for v in self.hyperparams.values())
+
     @property
     def v11(self):
-        if self._v11 is None:
+        # keyed on a snapshot of the hyper-parameter vector: the property setters (lambda_xi, variances, lengthscales)
+        # and direct edits of ``hyperparams`` are seen by every consumer -- host matrix, query context, model contexts
+        # and the device-built matrix of log_likelihood() always describe the same hyper-parameters.  A matrix assigned
+        # by hand stays until set_param_dict / set_param_vector.
+        if not self._v11_assigned and (self._v11 is None or self._v11_key != self._hyper_key()):
+            self._device = None
+            self._factor = None
+            self._v11_key = self._hyper_key()
             self._v11 = self.iPhiPhi / self.lambda_xi + batch_kernel(
                 self.grid_points, self.grid_points, self.variances, self.lengthscales
             )
@@ -161,6 +172,7 @@ class Emulator:
 
     # ----------------------------------------------------------------- query
     def _dev(self):
+        self.v11  # (drops a context built for other hyper-parameters)
         if self._device is None:
             z = np.zeros(0)
             self._device = D.DeviceOrder(
@@ -366,11 +378,15 @@ class Emulator:
         npad = -(-n // 64) * 64
         lda = npad + 16
         td = self._train_dev
-        if td is None or td["dev"] != dev or td["w_hat"] is not self.w_hat:
+        # resident training state, keyed on the identity of the arrays it was uploaded from: reassigning grid_points,
+        # iPhiPhi or w_hat re-uploads; after an IN-PLACE edit of one of them set ``emu._train_dev = None``
+        if (td is None or td["dev"] != dev or td["w_hat"] is not self.w_hat or td["grid_src"] is not self.grid_points
+                or td["iphiphi_src"] is not self.iPhiPhi):
             R = np.zeros(npad)
             R[:n] = self.w_hat
             td = self._train_dev = dict(
-                dev=dev, w_hat=self.w_hat, grid=D.to_dev(self.grid_points, dev), iphiphi=D.to_dev(self.iPhiPhi, dev),
+                dev=dev, w_hat=self.w_hat, grid_src=self.grid_points, iphiphi_src=self.iPhiPhi,
+                grid=D.to_dev(self.grid_points, dev), iphiphi=D.to_dev(self.iPhiPhi, dev),
                 R=D.to_dev(R, dev), A=D.empty((npad, lda), dev), out=D.empty((2,), dev), info=D.empty((1,), dev, torch.int32),
                 ws=D.workspace(lib.sf_potrf_workspace_bytes(npad, 1), dev),
             )

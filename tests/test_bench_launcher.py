@@ -86,3 +86,131 @@ def test_bench_gpus_2_on_a_one_gpu_box_fails_loudly():
         pytest.skip("needs exactly one visible GPU")
     r = _run(["--gpus", "2", "--npix", "256", "--batch", "32", "--steps", "1", "--warmup", "0"])
     assert r.returncode == 2 and "needs 2 visible GPUs, found 1" in r.stderr and not r.stdout.strip()
+
+
+def test_eight_way_order_major_split_of_cfg4():
+    """cfg 4 = the 1600 (order x walker) units of cfg 3 over 8 ranks: 200 units each, every rank owns walkers of at most
+    four orders (so at most four orders' static data per GPU), whole orders except at the ends of its slice, and the
+    ranks' slices tile the unit list in order (docs/intro.rst:71-73: orders / chains are independent)."""
+    from starfish_amd.parallel import order_major_slices, shard_range
+
+    n_orders, B, world = 25, 64, 8
+    owned = []
+    for r in range(world):
+        lo, hi = shard_range(n_orders * B, r, world)
+        assert hi - lo == 200
+        sl = order_major_slices(n_orders, B, lo, hi)
+        orders = [o for o, _, _ in sl]
+        assert orders == sorted(set(orders)) and len(orders) <= 4
+        assert orders == list(range(orders[0], orders[-1] + 1))            # a contiguous run of orders
+        assert all((a, b) == (0, B) for _, a, b in sl[1:-1])              # whole orders in the middle
+        assert sl[0][0] * B + sl[0][1] == lo and sl[-1][0] * B + sl[-1][2] == hi
+        owned.append(orders)
+    assert owned[0][0] == 0 and owned[-1][-1] == n_orders - 1
+    # an order is shared by at most two neighbouring ranks
+    for o in range(n_orders):
+        holders = [r for r in range(world) if o in owned[r]]
+        assert 1 <= len(holders) <= 2 and holders == list(range(holders[0], holders[-1] + 1))
+
+
+def test_rank_0_prints_one_parsable_line_when_the_run_fails():
+    """Without a GPU (this container) the run cannot start: the exit code says so AND stdout carries exactly one JSON
+    line with an `error` key and the contract's fields, so a driver that only parses stdout sees why."""
+    if _gpus() > 0:
+        pytest.skip("a GPU is visible: the failure path is covered by the -m gpu launcher tests")
+    r = _run(["--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 1 and d["unit"] == "evals/s" and "error" in d
+    assert "MI355X" in d["error"]
+
+
+_SMALL = ["--npix", "512", "--batch", "16", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-structured"]
+_ONE_RANK = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "SF_BENCH_FORCE_GROUP": "1"}
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+@pytest.mark.gpu
+def test_bench_runs_the_real_rccl_branch_with_one_rank():
+    """The N > 1 code path on the one-GPU box: RCCL accepts a single rank, so init (gloo control group + nccl group on
+    the device bound by LOCAL_RANK), the trial all-reduce, barrier, max-over-ranks, the clock-probe-before-the-group
+    order and the second scaling leg all execute for real."""
+    if _gpus() < 1:
+        pytest.skip("no GPU")
+    r = _run(["--gpus", "1"] + _SMALL, env=dict(_ONE_RANK, MASTER_PORT=_free_port()))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["process_group"].startswith("nccl"), d["process_group"]
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "error" not in d
+    assert d["strong"]["value"] > 0 and d["strong"]["units_per_gpu"] == 16
+    assert "before the process group" in d["roofline"]["sustained_clock_note"]
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_gloo_when_rccl_cannot_be_brought_up():
+    if _gpus() < 1:
+        pytest.skip("no GPU")
+    r = _run(["--gpus", "1"] + _SMALL, env=dict(_ONE_RANK, MASTER_PORT=_free_port(), SF_BENCH_FAIL_NCCL="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["process_group"].startswith("gloo (fallback") and d["value"] > 0
+    assert "RCCL group unavailable" in r.stderr
+
+
+@pytest.mark.gpu
+def test_a_failing_rank_still_leaves_one_parsable_line_from_rank_0():
+    """Rank 1 dies before the process group exists; the launcher terminates rank 0, which may sit in the rendezvous:
+    its watchdog thread prints the error line (with rank 1's message) and the launcher's exit code is non-zero."""
+    if _gpus() < 1:
+        pytest.skip("no GPU")
+    r = _run(["--gpus", "2"] + _SMALL, env={"SF_BENCH_RANKS_SHARE_GPU": "1", "SF_BENCH_FAIL_RANK": "1"}, timeout=900)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "error" in d
+    assert "rank1" in d["error"] and "SF_BENCH_FAIL_RANK" in d["error"]
+
+
+def test_watchdog_thread_prints_the_error_line_on_sigterm(tmp_path):
+    """Rank 0 blocked (here: in a lock; on the node: inside a collective or the rendezvous) when the launcher
+    terminates it: the wake-up byte of SIGTERM reaches the watchdog thread, which prints the line with the failed
+    rank's message and exits 143.  Pure host logic: runs without a GPU."""
+    import signal
+    import time
+
+    port = _free_port()
+    script = tmp_path / "blocked_rank0.py"
+    script.write_text(f"""
+import argparse, os, sys, tempfile, threading
+sys.path.insert(0, {ROOT!r})
+import bench
+os.environ["MASTER_PORT"] = {port!r}
+args = argparse.Namespace(config="cfg2", npix=None, batch=None, steps=1, warmup=0, scaling="weak")
+line = bench.ErrorLine(args, 0, 2)
+with open(os.path.join(line.dir, "rank1.err"), "w") as fh:
+    fh.write("rank 1: RuntimeError: boom")
+sys.stderr.write("ready\\n"); sys.stderr.flush()
+lock = threading.Lock(); lock.acquire(); lock.acquire()
+""")
+    p = subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.stderr.readline().strip() == "ready"
+    time.sleep(0.2)
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=60)
+    assert p.returncode == 143
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] is None and "rank1: rank 1: RuntimeError: boom" in d["error"]

@@ -308,3 +308,120 @@ def test_cov_fill_entry_point_matches_forward_and_reference():
     # the upper part may be written -- the factorisation never reads it)
     ii, jj = np.triu_indices(256, 128)
     assert not padded[0][:, 256:].any() and not padded[0][:, :256][ii, jj].any()
+
+
+@pytest.mark.parametrize("N,ld", [(3000, 3000), (250, 251)])
+def test_cov_fill_writes_only_the_callers_rows(N, ld):
+    """sf_cov_fill_batch into caller matrices of exactly n rows when n is not a multiple of 64 (cfg 3: 3000 -> the
+    workspace layout pads to 3008 with an identity block; a caller's array has no such rows): nothing lands in the
+    next matrix or behind the last one, lower triangle = the full fill's, with ld = n and with an odd ld."""
+    o = synth.make_order(N=N, m=4, seed=9)
+    do = device_order(oracle_order(o))
+    plist = [synth.vector_to_oracle_params(p) for p in synth.walker_ball(o, B=2, seed=4)]
+    md, rows = pack_rows(do, plist)
+    full, info = do.cov_fill(md, rows, add_jitter=True)
+    assert (info == 0).all()
+    low, info, guard = do.cov_fill(md, rows, ld=ld, lower_only=True, add_jitter=True, guard=64 * ld + 4096)
+    assert (info == 0).all() and low.shape == (2, N, ld)
+    assert (guard == -7.0).all()                       # nothing behind the last matrix
+    lo = np.tril_indices(N)
+    for b in range(2):
+        np.testing.assert_array_equal(low[b][:, :N][lo], full[b][lo])
+        assert not low[b][:, N:].any()                 # padding columns untouched
+        ii, jj = np.triu_indices(N, 128)
+        assert not low[b][:, :N][ii, jj].any()         # nothing a whole tile above the diagonal
+    # the first rows of matrix 1 hold matrix 1's own values (the identity padding of matrix 0 used to land here)
+    assert low[1][0, 0] == full[1][0, 0] and not low[1][0, 1:64].any()
+
+
+def _zero_noise_model(N):
+    """cfg-2 style order whose data carry NO pixel noise (sigma = 0): C = Y^T Y + K_global + K_local + 1e-10 I.  With a
+    calibration ``log_scale`` of 18 the rank-m term is ~1e15 times larger than everything else and its rounding noise
+    swamps the rest: C is numerically singular and numpy / LAPACK stop at the (m+1)-th pivot (checked on the oracle:
+    "9-th leading minor of the array is not positive definite") -- finite parameters, the case the reference meets at
+    spectrum_model.py:400."""
+    o = dict(synth.make_order(N=N))
+    o["sigma"] = np.zeros(N)
+    return o, synth.build_model(o)
+
+
+@pytest.mark.parametrize("chol_sequence", ["wide", "fused"], indirect=True)
+def test_non_positive_definite_walkers_in_a_full_batch(chol_sequence):
+    """SURVEY 5 / 8(b), reference spectrum_model.py:400 (cho_factor raises LinAlgError): in a batch the walkers whose
+    covariance is not positive definite come back as -inf with info = LAPACK's pivot index, every other walker is
+    bit-identical to the same batch without them; the scalar API raises numpy.linalg.LinAlgError like the reference."""
+    N, B, bad = 4096, 128, (5, 127)
+    o, model = _zero_noise_model(N)
+    P = synth.walker_ball(o, B=B, seed=21)
+    Pbad = P.copy()
+    Pbad[list(bad), 2] = 18.0
+    good, info0 = model.log_likelihood_batch(P, return_info=True)
+    assert (info0 == 0).all() and np.isfinite(good).all()
+    got, info = model.log_likelihood_batch(Pbad, return_info=True)
+    m = 8
+    for b in range(B):
+        if b in bad:
+            assert got[b] == -np.inf and m < info[b] <= m + 8, (b, got[b], info[b])  # oracle / LAPACK: the 9-th minor
+        else:
+            assert info[b] == 0 and got[b] == good[b], (b, got[b], good[b])
+    oo = oracle_order(o)
+    for b in (0, 126):
+        assert close_lnl(got[b], O.log_likelihood(oo, synth.vector_to_oracle_params(P[b])))
+    with pytest.raises(np.linalg.LinAlgError):
+        O.log_likelihood(oo, synth.vector_to_oracle_params(Pbad[5]))
+    # scalar API: raises like the reference; the model stays usable afterwards
+    model.set_param_vector(Pbad[5])
+    with pytest.raises(np.linalg.LinAlgError, match="leading minor"):
+        model.log_likelihood()
+    model.set_param_vector(P[5])
+    assert model.log_likelihood() == pytest.approx(good[5], rel=1e-12)
+
+
+@pytest.mark.parametrize("chol_sequence", ["wide", "fused"], indirect=True)
+def test_poisoned_covariance_buffers_report_lapack_pivot_indices(chol_sequence):
+    """sf_cov_fill_batch -> sf_potrf_batch at cfg 2's full size (128 x 4096): two matrices get a negative diagonal
+    entry at a known position -> info = that position + 1 (LAPACK's convention) for those two, 0 and bit-identical
+    factors for the rest."""
+    import torch
+    from starfish_amd import _device as D, _lib
+
+    gpu = _lib.require_gpu()
+    N, B = 4096, 128
+    lda = N + 16
+    o = synth.make_order(N=N)
+    do = device_order(oracle_order(o))
+    plist = [synth.vector_to_oracle_params(p) for p in synth.walker_ball(o, B=B, seed=3)]
+    md, rows = pack_rows(do, plist)
+    dev = do.dev
+    with torch.cuda.device(dev):
+        P = D.to_dev(rows, dev)
+        cov = torch.zeros((B, N, lda), dtype=torch.float64, device=dev)
+        info = D.empty((B,), dev, torch.int32)
+        ws = do._work(md, B)
+        s = D.stream_ptr(dev)
+        _lib.check(gpu.sf_cov_fill_batch(do.ctx, C_byref(md), B, D.ptr(P), D.ptr(cov), lda, N * lda, 1, 1, D.ptr(info),
+                                         D.ptr(ws), ws.numel(), s))
+        assert (info.cpu().numpy() == 0).all()
+        clean = cov.clone()
+        pw = D.workspace(gpu.sf_potrf_workspace_bytes(N, B), dev)
+        _lib.check(gpu.sf_potrf_batch(D.ptr(clean), N, lda, N * lda, B, D.ptr(info), D.ptr(pw), pw.numel(), s))
+        assert (info.cpu().numpy() == 0).all()
+        cov[5, 1000, 1000] = -1.0
+        cov[127, N - 1, N - 1] = -1.0
+        _lib.check(gpu.sf_potrf_batch(D.ptr(cov), N, lda, N * lda, B, D.ptr(info), D.ptr(pw), pw.numel(), s))
+        got = info.cpu().numpy()
+        want = np.zeros(B, dtype=got.dtype)
+        want[5], want[127] = 1001, N
+        np.testing.assert_array_equal(got, want)
+        keep = [b for b in range(B) if b not in (5, 127)]
+        tri = torch.tril(torch.ones((N, N), dtype=torch.bool, device=dev))
+        for b in keep[::9] + [4, 6, 126]:
+            assert torch.equal(cov[b, :, :N][tri], clean[b, :, :N][tri]), b
+        # matrix 5: everything left of the failing column is still the factor
+        assert torch.equal(torch.tril(cov[5, :1000, :1000]), torch.tril(clean[5, :1000, :1000]))
+
+
+def C_byref(md):
+    import ctypes
+
+    return ctypes.byref(md)

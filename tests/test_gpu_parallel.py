@@ -57,7 +57,7 @@ def _worker(rank, world, port, out_dir):
 def test_two_ranks_shard_real_models(tmp_path):
     world = 2
     ctx = mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
-    # bounded wait: a box on which two processes cannot bring the one GPU up together must not wedge the suite
+    # bounded wait: a wedged N > 1 path fails the test (it must not wedge the suite, and it must not pass as a skip)
     import time
 
     deadline = time.time() + 300
@@ -69,7 +69,7 @@ def test_two_ranks_shard_real_models(tmp_path):
     if not done:
         for p in ctx.processes:
             p.terminate()
-        pytest.skip("the two GPU worker processes did not finish within 300 s on this box")
+        pytest.fail("the two GPU worker processes did not finish within 300 s: the N > 1 path hangs")
     # the same evaluations in this process, unsharded
     o = synth.make_order(N=512, m=4, seed=21)
     want = synth.build_model(o).log_likelihood_batch(synth.walker_ball(o, B=11, seed=4))
@@ -141,7 +141,7 @@ def test_cfg4_order_major_split_two_ranks_vs_reference_goldens(tmp_path):
     if not done:
         for p in ctx.processes:
             p.terminate()
-        pytest.skip("the two GPU worker processes did not finish within 600 s on this box")
+        pytest.fail("the two GPU worker processes did not finish within 600 s: the N > 1 path hangs")
     g = load_golden("model_cfg3.npz")
     want = g["lnl"]
     for r in range(world):

@@ -99,6 +99,33 @@ def test_emulator_hyper_parameters_and_persistence(tmp_path):
         assert np.array_equal(getattr(back, attr), getattr(emu, attr)), attr
 
 
+def test_v11_follows_every_way_of_changing_the_hyper_parameters():
+    """One matrix for every consumer (the reference uses self.v11 for queries and likelihood alike, emulator.py:126-128,
+    569-571, 612): the property setters and direct edits of ``hyperparams`` invalidate the cached host matrix (and with
+    it the query context / factor), not only set_param_dict."""
+    emu = make_emulator()
+
+    def expect():
+        return emu.iPhiPhi / emu.lambda_xi + batch_kernel(emu.grid_points, emu.grid_points, emu.variances, emu.lengthscales)
+
+    first = emu.v11
+    assert emu.v11 is first                       # cached while nothing changes
+    emu.lambda_xi = 2.5
+    assert emu.v11 is not first and np.array_equal(emu.v11, expect())
+    emu.variances = 2e4 * np.ones(emu.ncomps)
+    assert np.array_equal(emu.v11, expect())
+    emu.lengthscales = 1.5 * emu.lengthscales
+    assert np.array_equal(emu.v11, expect())
+    emu.hyperparams["log_variance:0"] += 0.25
+    assert np.array_equal(emu.v11, expect())
+    mine = np.eye(len(first))
+    emu.v11 = mine                                # a matrix assigned by hand stays until the next set_param_dict
+    emu.lambda_xi = 1.0
+    assert np.array_equal(emu.v11, mine)
+    emu.set_param_dict(emu.get_param_dict())
+    assert np.array_equal(emu.v11, expect())
+
+
 def test_order_and_spectrum_dunders_and_persistence(tmp_path):
     wave = np.linspace(1e4, 2e4, 200)
     flux = np.sin(wave)

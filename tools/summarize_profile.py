@@ -85,6 +85,8 @@ for k, v in agg.items():
     if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and sqdur[k] > 0:
         # busy cycles summed over the 1024 SIMDs / (SIMDs x kernel time x 2.25 GHz sustained clock)
         e["mfma_pipe_busy_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * sqdur[k] * 1e-3 * 2.25e9), 3)
+    if "fetch_GB_per_step_corrected_x2" in e or "write_GB_per_step" in e:
+        e["hbm_bytes_per_launch"] = (e.get("fetch_GB_per_step_corrected_x2", 0) + e.get("write_GB_per_step", 0)) * 1e9 / max(1.0, e["launches_per_step"])
     summary[k] = e
 g = [k for k in summary if any(k.startswith(p) for p in PANEL)]
 tot_fetch = sum(summary[k].get("fetch_GB_per_step_corrected_x2", 0) for k in g)
@@ -98,6 +100,13 @@ summary["_k_chol_panel_all"] = {
 }
 if union:
     summary["_k_chol_panel_all"]["kernel_trace"] = union
+try:  # the id of the code the counters were collected on (bench.py reports the same id in its line)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+
+    summary["_code_id"] = bench.code_id()
+except Exception as e:  # pragma: no cover
+    summary["_code_id"] = None
 json.dump(summary, open(dst + "_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(summary["_k_chol_panel_all"]))
 for k in sorted(summary):
