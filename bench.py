@@ -507,7 +507,7 @@ class ErrorLine:
         import tempfile
         import threading
 
-        self.args, self.rank, self.world, self.printed = args, rank, world, False
+        self.args, self.rank, self.world, self.printed, self.terminated = args, rank, world, False, False
         self.lock = threading.Lock()
         tag = os.environ.get("MASTER_PORT") or str(os.getppid())
         self.dir = os.path.join(tempfile.gettempdir(), f"sf_bench_errors_{tag}")
@@ -519,6 +519,7 @@ class ErrorLine:
                 self.rd, wr = socket.socketpair()
                 wr.setblocking(False)
                 signal.signal(signal.SIGTERM, lambda *a: None)
+                signal.siginterrupt(signal.SIGTERM, False)  # SA_RESTART: the signal must not fail a HIP ioctl with EINTR
                 signal.set_wakeup_fd(wr.fileno(), warn_on_full_buffer=False)
                 self._wr = wr
                 threading.Thread(target=self._watch, daemon=True).start()
@@ -533,6 +534,7 @@ class ErrorLine:
             if not b:
                 return
             if signal.SIGTERM in b:
+                self.terminated = True
                 time.sleep(0.5)  # let the failing rank finish writing its error file
                 self.emit("terminated by the launcher (SIGTERM): another rank failed" + self._others())
                 os._exit(143)
@@ -572,6 +574,10 @@ class ErrorLine:
         msg = f"rank {self.rank}: {type(exc).__name__}: {exc}"
         sys.stderr.write(traceback.format_exc())
         if self.rank == 0:
+            if self.world > 1:  # an error caused by the launcher's SIGTERM: the watchdog's line names the real culprit
+                time.sleep(0.3)
+                if self.terminated:
+                    time.sleep(5.0)  # (the watchdog prints and exits the process)
             self.emit(msg)
         else:
             try:

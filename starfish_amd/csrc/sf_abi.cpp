@@ -659,6 +659,9 @@ struct Work {
     unsigned char* tilemap;
     unsigned short* tilelist;  // compact list of the materialised tiles (see sf_fill_args)
     int* tilecount;
+    unsigned char* dmap;       // dense fill of caller matrices: structured-support map / list of 64 x 64 tiles
+    unsigned short* dlist;
+    int* dcount;
     size_t bytes, ltbuf_stride;
     Layout L;
     int trans_bt = 0;      // walkers one set of transient buffers is sized for
@@ -701,6 +704,9 @@ static Work carve(const Layout& L, const sf_model_desc* mdl, int B, int Bt, void
     w.tilelist = need_C ? k.take<unsigned short>(b * tilemap_bytes(L)) : nullptr;  // (capacity: every tile)
     w.tilecount = need_C ? k.take<int>(b) : nullptr;
     w.gtab = need_C ? k.take<double>(b * (size_t)L.npad) : nullptr;
+    w.dmap = k.take<unsigned char>(b * sf_fill_dense_map_tiles(L.npad));
+    w.dlist = k.take<unsigned short>(b * sf_fill_dense_map_tiles(L.npad));
+    w.dcount = k.take<int>(b);
     w.C = need_C ? k.take<double>(b * (size_t)L.npad * L.lda) : nullptr;
     w.bytes = sf_align_up(k.off, 256);
     return w;
@@ -731,6 +737,9 @@ static Work slice(const Work& w, int u0) {
     if (s.tilelist) s.tilelist += u * tilemap_bytes(L);
     if (s.tilecount) s.tilecount += u;
     if (s.gtab) s.gtab += u * (size_t)L.npad;
+    if (s.dmap) s.dmap += u * sf_fill_dense_map_tiles(L.npad);
+    if (s.dlist) s.dlist += u * sf_fill_dense_map_tiles(L.npad);
+    if (s.dcount) s.dcount += u;
     if (s.C) s.C += u * (size_t)L.npad * L.lda;
     return s;
 }
@@ -987,7 +996,9 @@ extern "C" int sf_forward_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
     f.stride = (int64_t)c->n * c->n;
     f.lower_only = 0;
     f.add_jitter = 0;
-    rc = sf_launch_fill(f, B, s);
+    rc = sf_exec_prepare(&c->exec);
+    if (rc) return rc;
+    rc = sf_launch_fill_dense(f, B, w.dmap, w.dlist, w.dcount, s, &c->exec);
     if (rc) return rc;
     if (d_info) SF_HIP(hipMemcpyAsync(d_info, w.info_e, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, s));
     return SF_OK;
@@ -1020,7 +1031,9 @@ extern "C" int sf_cov_fill_batch(sf_ctx* c, const sf_model_desc* mdl, int B, con
         f.lower_only = lower_only ? 1 : 0;
         f.add_jitter = add_jitter ? 1 : 0;
         f.nout = c->n;  // the caller's matrices have n rows: no identity padding (it belongs to the workspace layout only)
-        rc = sf_launch_fill(f, B, s);
+        rc = sf_exec_prepare(&c->exec);
+        if (rc) return rc;
+        rc = sf_launch_fill_dense(f, B, w.dmap, w.dlist, w.dcount, s, &c->exec);  // (lower_only: the tile grid of sf_launch_fill)
         if (rc) return rc;
     }
     if (d_info) SF_HIP(hipMemcpyAsync(d_info, w.info_e, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, s));

