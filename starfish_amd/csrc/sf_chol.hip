@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "sf_common.h"
+#include <stdio.h>
 
 #ifdef SF_TUNING
 #define SF_PANEL_SKIPS(g, bit) ((g).skip & (bit))  // phase switched off (wrong results, timing only)
@@ -925,19 +926,19 @@ __global__ __launch_bounds__(NT) void k_diag_mfma(double* __restrict__ T, int64_
 // W = L^-T is row k of L^-1, and row k of L is read for the last time at step k -- by the waves that update block column
 // k and by the waves that accumulate row k of the inverse, all before that step's first barrier -- so after it the
 // inverse waves drop X(e, k) into the slot of L(k, e).  L leaves for global memory block by block as it becomes final.
-__global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, int64_t sT, int pw, int* __restrict__ info,
-                                                  int info_off, double* __restrict__ rhs, int ldr,
-                                                  double* __restrict__ Cdiag, int ldc, int64_t sC,
-                                                  double* __restrict__ Wt, int64_t sW, int fp0, int prio) {
+// (body shared by the kernel below and by the diagonal-tile tasks of k_potrf_dataflow; dsm: SF_DIAG_LDS_BYTES of LDS)
+__device__ __forceinline__ void sf_diag_lds_body(const double* __restrict__ T, int64_t sT, int pw, int* __restrict__ info,
+                                                 int info_off, double* __restrict__ rhs, int ldr,
+                                                 double* __restrict__ Cdiag, int ldc, int64_t sC,
+                                                 double* __restrict__ Wt, int64_t sW, int fp0, const int b,
+                                                 double* __restrict__ dsm, const int tid) {
     // fp0: the first fp0 rows / columns of the tile are virtual (identity in T; Cdiag and rhs point fp0 elements BEFORE
     // the matrix there: never stored, read as zero) -- the first tile of a shifted frame, see sf_potrf_front_pad
-    extern __shared__ double dsm[];
-    if (prio) __builtin_amdgcn_s_setprio(2);
     double* Tl = dsm;              // lower blocks (bi >= bj) of the tile at (bi (bi + 1) / 2 + bj) * DBS
     double* El = Tl;               // blocks X(e, j), e <= j, of W = L_kk^-T: in the slot of L(j, e) once row j of L is dead
     double* Fb = Tl + 36 * DBS;    // inverse of the current 16 x 16 diagonal factor
     double* rz = Fb + DBS;         // [128]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int nb = pw >> 4;
@@ -1061,6 +1062,14 @@ __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, 
         }
     }
 }
+__global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, int64_t sT, int pw, int* __restrict__ info,
+                                                  int info_off, double* __restrict__ rhs, int ldr,
+                                                  double* __restrict__ Cdiag, int ldc, int64_t sC,
+                                                  double* __restrict__ Wt, int64_t sW, int fp0, int prio) {
+    extern __shared__ double dsm[];
+    if (prio) __builtin_amdgcn_s_setprio(2);
+    sf_diag_lds_body(T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc, sC, Wt, sW, fp0, blockIdx.x, dsm, threadIdx.x);
+}
 static const int chain_prio = SF_TUNE_INT("SF_CHAIN_PRIO", 1);  // tuning aid: 0 = the chain's workgroups at normal wave priority
 #define SF_DIAG_LDS_BYTES ((37 * DBS + 128) * sizeof(double))
 static int sf_launch_diag128(double* T, int64_t sT, int pw, int* info, int info_off, double* rhs, int ldr, double* Cdiag,
@@ -1131,7 +1140,59 @@ struct sf_panel_args {
     // column fp, the panel-0 accesses that would touch a virtual column are predicated.  0 for unshifted matrices.
     int fp;
     int prio;  // wave priority (s_setprio) of the whole workgroup: the chain's launches share their SIMDs with bulk workgroups
+    // dataflow sequence (k_potrf_dataflow): the K range of a partial-sum task ends at K slab kstop (0: at the panel); MODE 3
+    // (partial sums added, then the K slabs [ktail, panel) in the same workgroup) starts its own loop at ktail; before the
+    // triangular solve the workgroup waits until *wflag >= wval (the counter the diagonal-tile task publishes)
+    int kstop, ktail;
+    const int* wflag;
+    int wval;
+    int* abort_flag;
 };
+
+// The fields of a step that differ from task to task inside k_potrf_dataflow (everything else of sf_panel_args is constant
+// over a factorisation and stays in the kernel arguments: a per-task copy of the whole structure does not fit the SGPRs)
+struct sf_panel_task {
+    int k0, pw, row0, nslab, slab_step;
+    int ksplit, kchunk, kstop, ktail;
+    double* part;
+    const double* Wt;
+    int64_t sW;
+    double* Sout;
+    const int* wflag;
+    int wval;
+    int* abort_flag;
+    int* lds_int;  // one int of LDS for the wait's broadcast
+    int prio;
+};
+__device__ __forceinline__ sf_panel_task sf_task_of(const sf_panel_args& g) {
+    sf_panel_task q;
+    q.k0 = g.k0;
+    q.pw = g.pw;
+    q.row0 = g.row0;
+    q.nslab = g.nslab;
+    q.slab_step = g.slab_step;
+    q.ksplit = g.ksplit;
+    q.kchunk = g.kchunk;
+    q.kstop = g.kstop;
+    q.ktail = g.ktail;
+    q.part = g.part;
+    q.Wt = g.Wt;
+    q.sW = g.sW;
+    q.Sout = g.Sout;
+    q.wflag = g.wflag;
+    q.wval = g.wval;
+    q.abort_flag = g.abort_flag;
+    q.lds_int = nullptr;
+    q.prio = g.prio;
+    return q;
+}
+
+// a pointer the compiler must treat as wave-uniform (an SGPR pair): the operand base of the direct-to-LDS loads
+__device__ __forceinline__ const double* sf_uniform_ptr(const double* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const double*)(((unsigned long long)hi << 32) | lo);
+}
 
 // granule swizzle of the main loop's LDS image (see k_chol_panel)
 __device__ __forceinline__ int sf_swz(int row) {
@@ -1157,27 +1218,96 @@ __device__ __forceinline__ void sf_solve_step(sf_d4 (&acc)[2][4], const double* 
     }
 }
 
-template <bool RHS, int MODE>
-__global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
+// ---- dataflow sequence (k_potrf_dataflow): dependencies between workgroups of ONE launch ------------------------
+// A producer finishes its global stores, __syncthreads(), then ONE lane: agent-scope release (write-back of the XCD's L2),
+// s_waitcnt by hand (the compiler may drop its own when the wave's scoreboard is provably empty), relaxed agent-scope
+// store / add on a monotone counter.  A consumer: ONE lane polls the counter with relaxed agent-scope loads (L2-served,
+// s_sleep between polls), then ONE agent-scope acquire (invalidates this CU's L1), __syncthreads(), plain loads.
+// (/opt/skills/guides/MI355X_MICROARCH.md, "Valid forms".)  Every wait is bounded: after SF_DF_TIMEOUT_TICKS of the 100 MHz
+// wall clock the waiter raises the launch's abort flag, which every other wait and the task dispenser observe.
+#define SF_DF_TIMEOUT_TICKS 400000000LL  // 4 s
+__device__ __forceinline__ int sf_df_load(const int* flag) {
+    return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Waits until *f1 >= t1 and *f2 >= t2 and *f3 >= t3 (NULL flags are skipped), then ONE acquire for all of them.  `probe`
+// (optional) is only looked at, before the acquire: *probe_ok tells whether it had reached its target -- the data it guards
+// is then covered by this acquire and needs no wait of its own later.  Returns false when the launch is being aborted.
+// (s_okp: one int of LDS -- the kernels keep their LDS image at offset 0 of the workgroup's allocation, so no static __shared__
+// variable may exist beside the dynamic buffer: with sm at offset 16 the direct-to-LDS operand loads lose their alignment)
+__device__ __forceinline__ bool sf_df_wait(const int* f1, int t1, const int* f2, int t2, const int* f3, int t3,
+                                           const int* probe, int tprobe, bool* probe_ok, int* abort_flag, const int tid,
+                                           int* s_okp) {
+    if (tid == 0) {
+        int ok = 1;
+        auto ready = [&]() {
+            return (!f1 || sf_df_load(f1) >= t1) && (!f2 || sf_df_load(f2) >= t2) && (!f3 || sf_df_load(f3) >= t3);
+        };
+        if (!ready()) {
+            const long long t0 = wall_clock64();
+            unsigned it = 0;
+            for (;;) {
+                __builtin_amdgcn_s_sleep(4);
+                if (ready()) break;
+                if ((++it & 31) == 0) {
+                    if (sf_df_load(abort_flag) != 0 || wall_clock64() - t0 > SF_DF_TIMEOUT_TICKS) {
+                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+        }
+        if (probe && sf_df_load(probe) >= tprobe) ok |= 2;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *s_okp = ok;
+    }
+    __syncthreads();
+    const int ok = __builtin_amdgcn_readfirstlane(*s_okp);
+    __syncthreads();  // (s_ok is rewritten by the next wait)
+    if (probe_ok) *probe_ok = (ok & 2) != 0;
+    return (ok & 1) != 0;
+}
+__device__ __forceinline__ bool sf_df_wait(const int* flag, int target, int* abort_flag, const int tid, int* s_okp) {
+    return sf_df_wait(flag, target, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, abort_flag, tid, s_okp);
+}
+// call after __syncthreads(): every wave's stores have been issued and waited for
+__device__ __forceinline__ void sf_df_release() {
+#ifndef SF_EXP_DF_NORELEASE  // (timing experiment, stale reads possible: what do the L2 write-backs of the releases cost?)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void sf_df_set(int* flag, int value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sf_df_add(int* flag, int value) {
+    __hip_atomic_fetch_add(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// MODE 0: the whole step; 1: split-K partial sums only; 2: partial sums added in split order + steps 2-4; 3: as 2, with the
+// K slabs [g.ktail, panel) accumulated by this workgroup after the partial sums (dataflow sequence: the chain's step).
+// `id` = tile (MODE 1: tile * ksplit + split) index; sm / red: 4 * GT * GLD + 2 * GT doubles of LDS.
+// (GA: `const sf_panel_args`, or the same in the constant address space -- the kernel arguments of k_potrf_dataflow)
+template <bool RHS, int MODE, class GA>
+__device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, const int id, double* __restrict__ sm,
+                                              double (*red)[GT], const int tid) {
     constexpr int TM = 2, TN = 4;
-    __shared__ __attribute__((aligned(16))) double sm[4 * GT * GLD];
-    __shared__ double red[2][GT];
     double(*As)[GT * GLD] = (double(*)[GT * GLD]) sm;
     double(*Bs)[GT * GLD] = (double(*)[GT * GLD])(sm + 2 * GT * GLD);
     double* Ach = sm;  // 128 x CLD chunk buffer of the epilogue (aliases As)
 
-    const int id = sf_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = MODE == 1 ? id / g.ksplit : id;
-    const int sp = MODE == 1 ? id - tile * g.ksplit : 0;
-    const int b = tile / g.nslab;
-    const int sl = tile - b * g.nslab;
-    const int row0 = (g.xrow0 && sl == g.nslab - 1) ? g.xrow0 : g.row0 + sl * g.slab_step * GT;
+    // (integer division runs on the VALU: without the readfirstlane its wave-uniform results -- and every address and loop
+    // bound derived from them -- would live in VGPRs)
+    const int tile = __builtin_amdgcn_readfirstlane(MODE == 1 ? id / tk.ksplit : id);
+    const int sp = __builtin_amdgcn_readfirstlane(MODE == 1 ? id - tile * tk.ksplit : 0);
+    const int b = __builtin_amdgcn_readfirstlane(tile / tk.nslab);
+    const int sl = tile - b * tk.nslab;
+    const int row0 = (g.xrow0 && sl == tk.nslab - 1) ? g.xrow0 : tk.row0 + sl * tk.slab_step * GT;
     const int rows_here = min(GT, ((g.nband && row0 < g.nband) ? g.nband : g.n) - row0);
-    const int pw = g.pw, k0 = g.k0;
+    const int pw = tk.pw, k0 = tk.k0;
     const int cfp = k0 == 0 ? g.fp : 0;  // panel columns below cfp are virtual (zero below the diagonal tile)
-    if (g.prio) __builtin_amdgcn_s_setprio(2);
+    if (tk.prio) __builtin_amdgcn_s_setprio(2);
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // rows wm*32.., cols wn*64..; waves w and w + 4 share a SIMD: they get different column halves, because in
@@ -1205,18 +1335,22 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         // fragment once, rows 0-3 / 12-15 with one granule column and rows 4-11 with the column two further): with
         // t = (row >> 1) & 7, rows with t in {2,3,4,5} get t ^ 2, the others t -- 16 distinct 16-byte bank slots.
         const int grow = lane >> 3, gpos = lane & 7;  // row within the 8-row group, granule slot within the row
-        const double* Ag[2];
-        const double* Bg[2];
+        // (addresses = a wave-uniform base in SGPRs, advanced along K by scalar adds, + a 32-bit lane offset: four VGPRs
+        // instead of four 64-bit pointers advanced by VALU adds -- the kernel sits at the 128-VGPR limit, and a pointer that
+        // spills is reloaded inside the K loop, where the wait for the scratch load also waits for the operand loads)
+        unsigned Aoff[2], Boff[2];
+#ifdef SF_EXP_AL2  // timing only: every slab streams the rows of the panel's first slab (L2-resident A operand)
+        const double* Abase = sf_uniform_ptr(Cb + (int64_t)(k0 + (k0 + 2 * GT <= g.n ? GT : 0)) * g.lda);
+#else
+        const double* Abase = sf_uniform_ptr(Cb + (int64_t)row0 * g.lda);
+#endif
+        const double* Bbase = sf_uniform_ptr(Cb + (int64_t)k0 * g.lda);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int row = 16 * w + 8 * q + grow;
             const int c = gpos ^ sf_swz(row);
-#ifdef SF_EXP_AL2  // timing only: every slab streams the rows of the panel's first slab (L2-resident A operand)
-            Ag[q] = Cb + (int64_t)(k0 + (k0 + 2 * GT <= g.n ? GT : 0) + min(row, rows_here - 1)) * g.lda + 2 * c;
-#else
-            Ag[q] = Cb + (int64_t)(row0 + min(row, rows_here - 1)) * g.lda + 2 * c;
-#endif
-            Bg[q] = Cb + (int64_t)(k0 + min(row, pw - 1)) * g.lda + 2 * c;
+            Aoff[q] = (unsigned)(min(row, rows_here - 1) * g.lda + 2 * c) * 8u;
+            Boff[q] = (unsigned)(min(row, pw - 1) * g.lda + 2 * c) * 8u;
         }
         typedef __attribute__((address_space(3))) void* lds_ptr;
         double* A2 = sm;                // [2][128 x 16]
@@ -1224,19 +1358,19 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         // (inline asm: hipcc drains vmcnt(0) before the next LDS read of ANY buffer when it sees the builtin in
         // flight; the loads are therefore hidden from it and waited for by hand right before the barrier)
         const unsigned ldsA = (unsigned)(size_t)(lds_ptr)A2, ldsB = (unsigned)(size_t)(lds_ptr)B2;
-        auto glds16 = [&](const double* src, unsigned lds_dst) {
+        auto glds16 = [&](const double* sbase, unsigned voff, unsigned lds_dst) {
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
-                         : "v"(src), "s"(lds_dst)
+                         : "v"(voff), "s"(sbase), "s"(lds_dst)
                          : "memory");
         };
         auto gload = [&](int kt, int buf) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned off = (unsigned)(buf * GT * GK + (16 * w + 8 * q) * GK) * 8u;
-                glds16(Ag[q] + kt * GK, ldsA + off);
-                glds16(Bg[q] + kt * GK, ldsB + off);
+                glds16(sf_uniform_ptr(Abase + kt * GK), Aoff[q], ldsA + off);
+                glds16(sf_uniform_ptr(Bbase + kt * GK), Boff[q], ldsB + off);
             }
         };
         auto gwait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
@@ -1244,21 +1378,22 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         // band: the K loop starts at the first column where both operands can be non-zero (a band slab's own rows;
         // for the dense border rows the panel's rows decide -- what lies left of that was never even written)
         const int klo = g.kband ? min(max((row0 < g.nband ? row0 : k0) - g.kband, 0) / GK, nk_all) : min(g.fp / GK, nk_all);
-        const int kbeg = MODE == 1 ? min(klo + sp * g.kchunk, nk_all) : klo;
-        const int kend = MODE == 1 ? min(kbeg + g.kchunk, nk_all) : (MODE == 2 ? kbeg : nk_all);
+        const int nk_lim = (MODE == 1 && tk.kstop > 0) ? min(tk.kstop, nk_all) : nk_all;
+        const int kbeg = MODE == 1 ? min(klo + sp * tk.kchunk, nk_lim) : (MODE == 3 ? min(max(tk.ktail, klo), nk_all) : klo);
+        const int kend = MODE == 1 ? min(kbeg + tk.kchunk, nk_lim) : (MODE == 2 ? kbeg : nk_all);
         const int nk = kend - kbeg;
         if (nk > 0) gload(kbeg, 0);
 
         bool generate = false;
         if (g.tilemap) generate = !g.tilemap[(int64_t)b * g.nt128 * g.nt128 + (row0 / GT) * g.nt128 + k0 / GT];
-        if (MODE == 2) {
+        if (MODE == 2 || (MODE == 3 && tk.ksplit > 0)) {
             // the partial sums of the split-K workgroups, added in split order
-            const double* P = g.part + (int64_t)tile * g.ksplit * (GT * GT);
+            const double* P = tk.part + (int64_t)tile * tk.ksplit * (GT * GT);
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (sf_d4){0.0, 0.0, 0.0, 0.0};
-            for (int q = 0; q < g.ksplit; ++q) {
+            for (int q = 0; q < tk.ksplit; ++q) {
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -1405,7 +1540,7 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         if (nk > 0) compute((nk - 1) & 1);
         __syncthreads();  // the epilogue re-uses the LDS with its own layouts
         if (MODE == 1) {
-            double* P = g.part + ((int64_t)tile * g.ksplit + sp) * (GT * GT);
+            double* P = tk.part + ((int64_t)tile * tk.ksplit + sp) * (GT * GT);
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -1416,12 +1551,14 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             return;
         }
 
+        // (dataflow sequence: the long-K loop above did not need the diagonal tile's factor; everything below does)
+        if (tk.wflag && !sf_df_wait(tk.wflag, tk.wval, tk.abort_flag, tid, tk.lds_int)) return;
         // ---------------------------------------------------------------- 2: L = T W through LDS
         const int nsb = SF_PANEL_SKIPS(g, 1) ? 0 : pw >> 4;  // 16-column blocks of the panel (4 or 8)
         const double* Wp[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            Wp[p] = g.Wt + (int64_t)b * g.sW + (int64_t)min(lr + 64 * p, pw - 1) * SF_LDT + lc;
+            Wp[p] = tk.Wt + (int64_t)b * tk.sW + (int64_t)min(lr + 64 * p, pw - 1) * SF_LDT + lc;
         double2 rw[2];
         auto wload = [&](int sb) {
 #pragma unroll
@@ -1586,8 +1723,8 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
             __syncthreads();
         }
         if (nk2 > 0) compute2((nk2 - 1) & 1);
-        const bool parked = g.Sout && sl == 0;  // (only the first slab of a launch is the next diagonal tile)
-        double* So = parked ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
+        const bool parked = tk.Sout && sl == 0;  // (only the first slab of a launch is the next diagonal tile)
+        double* So = parked ? tk.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
         const int ldo = parked ? g.ldS : g.lda;
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
@@ -1603,6 +1740,13 @@ __global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
         __syncthreads();
         if (tid < rows_here) g.rhs[(int64_t)b * g.ldr + row0 + tid] -= red[0][tid] + red[1][tid];
     }
+}
+
+template <bool RHS, int MODE>
+__global__ __launch_bounds__(512, 4) void k_chol_panel(sf_panel_args g) {
+    __shared__ __attribute__((aligned(16))) double sm[4 * GT * GLD];
+    __shared__ double red[2][GT];
+    sf_panel_body<RHS, MODE>(g, sf_task_of(g), sf_xcd_remap(blockIdx.x, gridDim.x), sm, red, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1682,25 +1826,27 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
         const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smw;
         const int grow = lane >> 3, gpos = lane & 7;
         // 384 rows of 8 granules per stage = 48 groups of 8 rows, three per wave; groups 0-15 are A rows, 16-47 B rows
-        const double* src[3];
+        // (a wave-uniform base advanced along K by scalar adds + 32-bit lane offsets: see k_chol_panel)
+        unsigned soff[3];
+        const double* sbase = sf_uniform_ptr(Cb + g.fp);  // (K starts at column fp)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int G = 3 * w + j;
             const bool isA = G < 16;
             const int r = (isA ? G : G - 16) * 8 + grow;
             const int c = gpos ^ sf_swz(r);
-            src[j] = Cb + (int64_t)(isA ? row0 + min(r, rows_here - 1) : k0 + r) * g.lda + g.fp + 2 * c;  // (K starts at column fp)
+            soff[j] = (unsigned)(((int64_t)(isA ? row0 + min(r, rows_here - 1) : k0 + r) * g.lda + 2 * c) * 8);
         }
-        auto glds16 = [&](const double* p, unsigned lds_dst) {
+        auto glds16 = [&](const double* sb, unsigned voff, unsigned lds_dst) {
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
-                         : "v"(p), "s"(lds_dst)
+                         : "v"(voff), "s"(sb), "s"(lds_dst)
                          : "memory");
         };
         auto gload = [&](int kt, int stage) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) glds16(src[j] + kt * GK, lds0 + (unsigned)(stage * WST * 8 + (3 * w + j) * 1024));
+            for (int j = 0; j < 3; ++j) glds16(sf_uniform_ptr(sbase + kt * GK), soff[j], lds0 + (unsigned)(stage * WST * 8 + (3 * w + j) * 1024));
         };
         auto gwait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         const int nk = max(k0 - g.fp, 0) / GK;
@@ -2034,6 +2180,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
 #define SF_CHIP_WGS 512
 #define SF_SPLIT_MAX 8
 static size_t sf_split_region_tiles(void) { return 2 * SF_CHIP_WGS; }  // partial-sum tiles per region
+__device__ __forceinline__ size_t sf_split_region_tiles_dev(void) { return 2 * SF_CHIP_WGS; }
 static int sf_split_policy(long long wgs, int nk) {
     static const int force = SF_TUNE_INT("SF_CHOL_SPLIT", -1);  // tuning aid
     int S = 1;
@@ -2278,8 +2425,8 @@ static int sf_launch_potrf_v1(double* A, int n, int lda, int64_t stride, int bat
     } while (0)
 static std::atomic<int> g_chol_sequence{-1};
 int sf_set_cholesky_sequence(int mode) {
-    if (mode < -1 || mode > 3) {
-        sf_set_error("cholesky sequence: -1 automatic, 0 fused panel kernel, 1 unfused, 2 wide (panel pairs), 3 wide then narrow (test aid)");
+    if (mode < -1 || mode > 4) {
+        sf_set_error("cholesky sequence: -1 automatic, 0 fused panel kernel, 1 unfused, 2 wide (panel pairs), 3 wide then narrow (test aid), 4 dataflow");
         return SF_EINVAL;
     }
     g_chol_sequence.store(mode);
@@ -2860,6 +3007,522 @@ int sf_launch_potrf_band(int n, int nband, int halfwidth, int batch, const doubl
     return SF_OK;
 }
 
+
+// =====================================================================================================================
+// DATAFLOW sequence (round 4): the whole factorisation of a batch as ONE persistent launch.
+//
+// The launch sequences above are bound by their panel boundaries once the batch no longer fills the chip many times over
+// (cfg 2 split over 2 / 4 / 8 GPUs: 64 / 32 / 16 matrices): the chain D(k) -> top(k) -> D(k+1) waits for workgroup slots
+// behind bulk workgroups that start and end together, the bulk launches wait for the chain's events, every launch fills
+// and drains the chip on its own (timelines in profiles/r04_*: the three streams 85-90 % busy, the matrix cores 0.49-0.74).
+// Here 512 workgroups (two per CU) stay resident and draw TASKS from one counter; a task waits for exactly the tasks whose
+// results it reads (monotone counters in global memory, agent scope) -- nothing else orders the work:
+//   C(b,k)    chain task of matrix b: the step of slab k for panel k-1 -- the split-K partial sums PT(b,k-1,.) added in split
+//             order, then the K tail over the last 128 columns, solve, L in place, tile (k,k) parked -- and the diagonal tile
+//             D(b,k) right behind it in the SAME workgroup (the tile never leaves the CU's caches; one task, no slot wait)
+//   PT(b,k,s) partial sums of slab k+1 for panel k over the columns LEFT of panel k-1: they depend on rest tasks two stages
+//             back, so they run long before C(b,k) needs the row they complete -- the chain's critical path per panel is
+//             reduce + 8 K slabs + solve + diagonal tile (~170 us), not a long-K loop
+//   R(b,i,k)  the fused panel step of slab i >= k+2 (MODE 0: its K loop starts as soon as row k is final, only the
+//             triangular solve waits for D(b,k)), or, while a stage has fewer tasks than the chip has workgroup slots,
+//             RP(b,i,k,s) partial sums + RR(b,i,k) reduce + epilogue
+// Tasks are drawn in an order in which every dependency precedes its dependants (stage k: PT(.,k+1,.), first half of
+// R(.,.,k), C(.,k+1), second half); a workgroup holds at most one task and only claimed tasks are waited for, so the
+// schedule cannot deadlock whatever the residency or placement of the workgroups.  The inverse tiles W_k of ALL panels are
+// kept (one per panel in the scratch the unfused sequence uses for its panel): no buffer of the chain is ever recycled.
+// Same arithmetic as the fused sequence (same kernels' bodies); the summation order differs where the split differs.
+struct sf_df_stage {
+    int off;      // first task of the stage's segment
+    int St;       // split of PT(., k+1, .): 0 = the chain task runs the whole K loop itself
+    int Sr;       // split of the rest tasks (1 = unsplit MODE 0)
+    int thr_pt;   // PT(b, k+1, .) arrivals C(b, k+2) waits for (cumulative over the stages of the same parity)
+    int thr_rp;   // RP(b, i, k, .) arrivals RR(b, i, k) waits for (cumulative)
+    int dep;      // RP of this stage re-uses the partial-sum region of stage `dep` (same parity, split): wait for its reduces
+};
+template <class S>
+__host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy out of the constant address space)
+    sf_df_stage r;
+    r.off = x.off;
+    r.St = x.St;
+    r.Sr = x.Sr;
+    r.thr_pt = x.thr_pt;
+    r.thr_rp = x.thr_rp;
+    r.dep = x.dep;
+    return r;
+}
+// One task queue per XCD: matrix b belongs to queue b % 8 (its slabs share the B operand L[panel rows, :k0] through that
+// XCD's L2 -- with ONE queue for the chip the operand was fetched by every XCD: L2 hit rate 0.14 instead of 0.38, 1.5 x the
+// HBM reads, 66 ms instead of 50 for 128 matrices); a workgroup serves the queue of the XCD it runs on and, once that is
+// exhausted, the others in turn.  Queues with the same number of matrices share a task table (at most two sizes).
+#define SF_DF_QUEUES 8
+#define SF_DF_MAX_STAGES 64
+#define SF_DF_QTILES (2 * SF_CHIP_WGS / SF_DF_QUEUES)  // partial-sum tiles per queue and stage parity
+struct sf_df_args {
+    sf_panel_args p;  // matrix, right-hand side, generator, frame: the per-task fields are filled in by the kernel
+    int nt, batch;
+    int bq[2], ntasks[2];  // table v serves the queues with bq[v] matrices
+    int pt_cap;       // largest split of the chain's partial sums: a matrix owns pt_cap tiles per panel parity in region 2
+    int *head, *abort_flag, *done_top, *done_D, *done_row, *pt_cnt, *rp_cnt, *stage_done;
+    double* T;        // per matrix: parked diagonal tile [GT x SF_LDT], then W_k for every panel
+    int64_t sT;
+    double* part;     // three regions of sf_split_region_tiles() tiles: rest partial sums by stage parity, chain partial sums
+    int* info;
+    long long* dbg;   // tuning builds: per workgroup {ticks waiting, ticks in task bodies, ticks publishing, tasks} (100 MHz)
+    sf_df_stage st[2][SF_DF_MAX_STAGES];
+};
+#define SF_DF_LDS_DOUBLES ((37 * DBS + 128) > (4 * GT * GLD + 2 * GT) ? (37 * DBS + 128) : (4 * GT * GLD + 2 * GT))
+#define SF_DF_LDS_BYTES ((SF_DF_LDS_DOUBLES + 2) * sizeof(double))
+
+template <bool RHS>
+__global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    double* sm = dsm;
+    double(*red)[GT] = (double(*)[GT])(dsm + 4 * GT * GLD);
+    int* s_ints = (int*)(dsm + SF_DF_LDS_DOUBLES);  // [0] task id, [1] wait result: behind the kernels' LDS image, which starts at 0
+    const size_t region = sf_split_region_tiles_dev() * (size_t)(GT * GT);
+    // The arguments are read through the kernel-argument segment pointer inside the task loop, and everything derived from
+    // the thread index is recomputed per task (the index is laundered through an empty asm): otherwise hipcc hoists the
+    // lane-dependent invariants of all five inlined task bodies out of the loop and spills them (600 bytes of scratch per
+    // lane, scratch loads inside the MFMA loops).
+    typedef const __attribute__((address_space(4))) sf_df_args sf_df_kargs;
+    sf_df_kargs* ap = (sf_df_kargs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a_in;
+    // (workgroup b of a launch runs on XCD b % 8 -- observed, not promised; placement is a speed matter only here: any
+    // workgroup may serve any queue)
+    const unsigned xcc = blockIdx.x;
+    int qcur = (int)(xcc & (SF_DF_QUEUES - 1));
+    int visited = 0;
+    int kst = 0;  // stage hint: a workgroup draws the tasks of a queue in increasing order
+    for (;;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        sf_df_kargs& a = *ap;
+        const int nt = a.nt;
+        const int n = a.p.n, fp = a.p.fp;
+        const int B = (a.batch - qcur + SF_DF_QUEUES - 1) / SF_DF_QUEUES;  // matrices of this queue: qcur, qcur + 8, ...
+        const int v = B == a.bq[0] ? 0 : 1;
+        const int ntasks = B > 0 ? a.ntasks[v] : 0;
+        if (tid == 0) {
+            int t = -1;
+            if (sf_df_load(a.abort_flag) == 0)
+                t = ntasks > 0 ? __hip_atomic_fetch_add(a.head + qcur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ntasks;
+            s_ints[0] = t;
+        }
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(s_ints[0]);  // (wave-uniform: everything decoded from it lives in SGPRs)
+        __syncthreads();
+        if (t < 0) {  // a wait timed out somewhere: nothing of this launch can be trusted
+            if (a.info)
+                for (int bb = tid; bb < a.batch; bb += 512) a.info[bb] = SF_INFO_INTERNAL;
+            return;
+        }
+        if (t >= ntasks) {  // this queue is exhausted: the next one
+            if (++visited == SF_DF_QUEUES) return;
+            qcur = (qcur + 1) & (SF_DF_QUEUES - 1);
+            kst = 0;
+            continue;
+        }
+
+        // ---- decode
+        enum { T_C, T_PT, T_R, T_RP, T_RR };
+        int type, bl, k, i = 0, sp = 0, S = 1;
+        // rest tile -> (slab, matrix): the two slabs the chain needs next come first, for every matrix; the others matrix by
+        // matrix, so that the tasks running side by side on an XCD stream the SAME B operand L[panel rows, :k0] more or
+        // less in step (slab-major order: 16 matrices x 2 MB of B operand in flight per XCD -- nothing of it survives in the L2)
+        auto rest_tile = [&](int tile, int kk, int nrest) {
+            const int lead = min(nrest, 2);
+            if (tile < lead * B) {
+                i = kk + 2 + tile / B;
+                bl = tile % B;
+            } else {
+                const int u2 = tile - lead * B, per = nrest - lead;
+                bl = u2 / per;
+                i = kk + 2 + lead + (u2 - bl * per);
+            }
+        };
+        if (t < B) {
+            type = T_C;
+            bl = t;
+            k = 0;
+        } else {
+            while (kst + 1 < nt - 1 && t >= a.st[v][kst + 1].off) ++kst;
+            const sf_df_stage st = sf_df_stage_of(a.st[v][kst]);
+            const int nrest = nt - kst - 2;
+            const int n_pt = B * st.St;
+            const int n_r = B * nrest;
+            const int n_r1 = st.Sr > 1 ? n_r * st.Sr : (n_r + 1) / 2;
+            int u = t - st.off;
+            if (u < n_pt) {
+                type = T_PT;
+                k = kst + 1;  // partial sums of slab k+1 for panel k
+                S = st.St;
+                bl = u / S;
+                sp = u - bl * S;
+            } else if ((u -= n_pt) < n_r1) {
+                k = kst;
+                if (st.Sr > 1) {
+                    type = T_RP;
+                    S = st.Sr;
+                    const int tile = u / S;
+                    sp = u - tile * S;
+                    rest_tile(tile, k, nrest);
+                } else {
+                    type = T_R;
+                    rest_tile(u, k, nrest);
+                }
+            } else if ((u -= n_r1) < B) {
+                type = T_C;
+                bl = u;
+                k = kst + 1;
+            } else {
+                u -= B;
+                k = kst;
+                type = st.Sr > 1 ? T_RR : T_R;
+                S = st.Sr;
+                rest_tile(st.Sr > 1 ? u : n_r1 + u, k, nrest);
+            }
+        }
+        bl = __builtin_amdgcn_readfirstlane(bl);  // (the divisions above ran on the VALU)
+        i = __builtin_amdgcn_readfirstlane(i);
+        sp = __builtin_amdgcn_readfirstlane(sp);
+        k = __builtin_amdgcn_readfirstlane(k);
+        S = __builtin_amdgcn_readfirstlane(S);
+        type = __builtin_amdgcn_readfirstlane(type);
+        const int b = qcur + SF_DF_QUEUES * bl;  // the matrix
+#ifdef SF_TUNING
+        const long long dbg_t0 = wall_clock64();
+        long long dbg_t1 = dbg_t0;
+#define SF_DF_MARK() dbg_t1 = wall_clock64()
+#else
+#define SF_DF_MARK()
+#endif
+
+        // ---- the per-task fields of the panel step (a.p holds what is constant over the factorisation)
+        const auto& g = a.p;
+        sf_panel_task q = {};
+        q.nslab = 1;
+        q.slab_step = 1;
+        q.abort_flag = a.abort_flag;
+        q.lds_int = s_ints + 1;
+        q.sW = a.sT;
+        auto Wof = [&](int kk) { return a.T + (size_t)(1 + kk) * GT * SF_LDT; };
+        bool ok = true;
+        if (type == T_C) {
+            q.Sout = a.T;  // (g.sS = a.sT, g.ldS = SF_LDT)
+            if (k == 0) {
+                // start of the factorisation: diagonal tile 0 goes to the scratch unchanged (pw = 0)
+                if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __syncthreads();
+                sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
+            } else {
+                const int kp = k - 1;  // the step of slab k for panel kp
+                const sf_df_stage stp = sf_df_stage_of(a.st[v][kp > 0 ? kp - 1 : 0]);  // (PT(., kp, .) belongs to stage kp - 1)
+                const int St = kp >= 1 ? stp.St : 0;
+                q.k0 = kp * GT;
+                q.pw = min(GT, n - q.k0);
+                q.row0 = k * GT;
+                q.Wt = Wof(kp);
+                q.ksplit = St;
+                q.ktail = St > 0 ? (kp - 1) * (GT / GK) : 0;
+                q.part = a.part + 2 * region + ((size_t)(kp & 1) * a.batch * a.pt_cap + (size_t)b * (a.pt_cap - St)) * (GT * GT);
+                // row k left of the tail (rest task of stage kp - 1), the previous chain task (row kp, W_kp), the partial sums
+                ok = sf_df_wait(kp >= 1 ? a.done_row + (size_t)b * nt + k : nullptr, kp, a.done_D + b, kp + 1,
+                                St > 0 ? a.pt_cnt + 2 * b + (kp & 1) : nullptr, stp.thr_pt, nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
+                SF_DF_MARK();
+                if (ok) sf_panel_body<RHS, 3>(g, q, b, sm, red, tid);
+            }
+            if (ok) {
+                __syncthreads();
+                if (tid == 0) {  // row k is final through panel k-1; the parked tile must be re-read through the L2
+                    sf_df_release();
+                    sf_df_set(a.done_top + b, k);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const int k0 = k * GT;
+                const int pw = min(GT, n - k0);
+                sf_diag_lds_body(a.T, a.sT, pw, a.info, k0 - fp, g.rhs ? g.rhs + k0 : nullptr, g.ldr,
+                                 g.C + (int64_t)k0 * g.lda + k0, g.lda, g.sC, Wof(k), a.sT, k == 0 ? fp : 0, b, dsm, tid);
+                __syncthreads();
+                if (tid == 0) {
+                    sf_df_release();
+                    sf_df_set(a.done_D + b, k + 1);
+                }
+            }
+        } else {
+            const int k0 = k * GT;
+            const int nk = (k0 > fp ? k0 - fp : 0) / GK;
+            q.k0 = k0;
+            q.pw = min(GT, n - k0);
+            q.Wt = Wof(k);
+            if (type == T_PT) {
+                // slab k+1, panel k, K slabs [fp / GK, (k - 1) 8): rows k and k+1 through panel k-2; the region's previous user
+                const int cnt = (k - 1) * (GT / GK) - fp / GK;
+                q.row0 = (k + 1) * GT;
+                q.ksplit = S;
+                q.kchunk = (cnt + S - 1) / S;
+                q.kstop = (k - 1) * (GT / GK);
+                q.part = a.part + 2 * region + ((size_t)(k & 1) * a.batch * a.pt_cap + (size_t)b * (a.pt_cap - S)) * (GT * GT);
+                ok = sf_df_wait(a.done_row + (size_t)b * nt + k, k - 1, a.done_row + (size_t)b * nt + k + 1, k - 1, a.done_D + b, k,
+                                nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
+                SF_DF_MARK();
+                if (ok) {
+                    sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
+                    __syncthreads();
+                    if (tid == 0) {
+                        sf_df_release();
+                        sf_df_add(a.pt_cnt + 2 * b + (k & 1), 1);
+                    }
+                }
+            } else {
+                const sf_df_stage st = sf_df_stage_of(a.st[v][k]);
+                q.row0 = i * GT;
+                q.ksplit = S;
+                q.kchunk = (nk + S - 1) / S;
+                // (the body indexes the partial sums with the matrix number b: slot of (slab, local matrix) minus b S)
+                q.part = a.part + (size_t)(k & 1) * region +
+                         ((int64_t)qcur * SF_DF_QTILES + ((int64_t)(i - k - 2) * B + bl - b) * S) * (GT * GT);
+                int* rowflag = a.done_row + (size_t)b * nt + i;
+                int* sdone = a.stage_done + (size_t)qcur * nt;
+                if (type == T_R) {
+                    // K loop: row k through panel k-1 (the chain task's first half), the slab's own row through panel k-1; only
+                    // the solve needs the diagonal tile -- if that is there already, this acquire covers it
+                    bool dready = false;
+                    ok = sf_df_wait(k >= 1 ? a.done_top + b : nullptr, k, rowflag, k, nullptr, 0, a.done_D + b, k + 1, &dready,
+                                    a.abort_flag, tid, s_ints + 1);
+                    if (!dready) {
+                        q.wflag = a.done_D + b;
+                        q.wval = k + 1;
+                    }
+                    SF_DF_MARK();
+                    if (ok) sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
+                } else if (type == T_RP) {
+                    ok = sf_df_wait(k >= 1 ? a.done_top + b : nullptr, k, rowflag, k, st.dep >= 0 ? sdone + st.dep : nullptr,
+                                    B * (nt - st.dep - 2), nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
+                    SF_DF_MARK();
+                    if (ok) sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
+                } else {
+                    ok = sf_df_wait(a.rp_cnt + (size_t)b * nt + i, st.thr_rp, a.done_D + b, k + 1, nullptr, 0, nullptr, 0, nullptr,
+                                    a.abort_flag, tid, s_ints + 1);
+                    SF_DF_MARK();
+                    if (ok) sf_panel_body<RHS, 2>(g, q, b, sm, red, tid);
+                }
+                // (a workgroup that left the body on a timed-out wait finds the abort flag at the dispenser)
+                __syncthreads();
+                if (ok && tid == 0) {
+                    sf_df_release();
+                    if (type == T_RP) {
+                        sf_df_add(a.rp_cnt + (size_t)b * nt + i, 1);
+                    } else {
+                        sf_df_set(rowflag, k + 1);
+                        if (type == T_RR) sf_df_add(sdone + k, 1);
+                    }
+                }
+            }
+        }
+        if (!ok) continue;  // (timed out: the dispenser sees the abort flag and flags every matrix)
+        __syncthreads();  // the next task re-uses the LDS
+#ifdef SF_TUNING
+        if (a.dbg && tid == 0) {
+            const long long t2 = wall_clock64();
+            long long* d = a.dbg + 8 * (size_t)blockIdx.x;
+            d[0] += dbg_t1 - dbg_t0;
+            d[1] += t2 - dbg_t1;
+            d[2] += 1;
+            d[7] = 1 + (long long)(xcc & 0xffff) + ((long long)qcur << 16) + ((long long)visited << 24);
+            if (type == T_R) {  // per-stage totals of the unsplit rest tasks (body only, waits excluded)
+                atomicAdd((unsigned long long*)(a.dbg + 8 * SF_CHIP_WGS + 2 * k), (unsigned long long)(t2 - dbg_t1));
+                atomicAdd((unsigned long long*)(a.dbg + 8 * SF_CHIP_WGS + 2 * k + 1), 1ull);
+            }
+            d[3 + (type == T_C ? 0 : type == T_PT ? 1 : type == T_R ? 2 : type == T_RP ? 3 : 4)] += t2 - dbg_t0;
+        }
+#endif
+    }
+}
+
+// split factor of a stage's tasks: the largest power of two that keeps the stage within the workgroup slots of its queue's
+// XCD and every K chunk at 8 slabs or more
+static int sf_df_split(long long tasks, int nk, int smax, int cap) {
+    int S = 1;
+    while (2 * S <= smax && tasks * 2 * S <= cap && nk / (2 * S) >= 8) S *= 2;
+    return S;
+}
+
+static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
+                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, int fp) {
+    if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
+        sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
+        return SF_EINVAL;
+    }
+    static sf_dev_once attr_once;
+    SF_CHECK(sf_once_per_device(&attr_once, []() -> int {
+        SF_HIP(hipFuncSetAttribute((const void*)k_potrf_dataflow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_DF_LDS_BYTES));
+        SF_HIP(hipFuncSetAttribute((const void*)k_potrf_dataflow<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_DF_LDS_BYTES));
+        return SF_OK;
+    }));
+    double* T = work + (size_t)batch * SF_LTB_DOUBLES;
+    const int64_t sT = (int64_t)(n + SF_NB) * SF_LDT + SF_TSKEW;  // parked tile + one inverse tile per panel: (n + 64 + 128) rows
+    double* Wt2 = T + (size_t)batch * sT;
+    const int64_t sW = (int64_t)SF_NB * SF_LDT + SF_TSKEW;
+    double* part = Wt2 + 2 * (size_t)batch * sW + 64;
+    SF_SHIFT_FRAME();
+    const int nt = (n + GT - 1) / GT;
+    // counters: in the two inverse-tile buffers of the launch sequences (2 x batch x sW doubles), which this sequence does not use
+    int* flags = (int*)Wt2;
+    const size_t nflags = 64 + (size_t)batch * (2 * nt + 4) + (size_t)SF_DF_QUEUES * nt + 2 * 10 * SF_CHIP_WGS + 8;
+    if (nt - 1 > SF_DF_MAX_STAGES || nflags * sizeof(int) > 2 * (size_t)batch * sW * sizeof(double)) {
+        sf_set_error("potrf: dataflow sequence: %d panels / %d matrices do not fit its tables", nt, batch);
+        return SF_EINVAL;
+    }
+    sf_df_args a = {};
+    a.head = flags;  // [SF_DF_QUEUES]
+    a.abort_flag = flags + 32;
+    a.done_top = flags + 64;
+    a.done_D = a.done_top + batch;
+    a.pt_cnt = a.done_D + batch;            // [batch][2]
+    a.done_row = a.pt_cnt + 2 * batch;      // [batch][nt]
+    a.rp_cnt = a.done_row + (size_t)batch * nt;
+    a.stage_done = a.rp_cnt + (size_t)batch * nt;  // [SF_DF_QUEUES][nt]
+    SF_HIP(hipMemsetAsync(flags, 0, nflags * sizeof(int), s));
+    SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
+
+    sf_panel_args& g = a.p;
+    g.C = A;
+    g.sC = stride;
+    g.lda = lda;
+    g.n = n;
+    g.rhs = rhs;
+    g.ldr = ldr;
+    g.fp = fp;
+    g.sS = sT;  // (the parked diagonal tile of matrix b: T + b sT, row stride SF_LDT)
+    g.ldS = SF_LDT;
+#ifdef SF_TUNING
+    static const int skip = SF_TUNE_INT("SF_PANEL_SKIP", 0);
+    g.skip = skip;
+#endif
+    if (gen) {
+        g.genY = gen->Y - fp;
+        g.sY = (int64_t)gen->mpad * gen->ldy;
+        g.ldy = gen->ldy;
+        g.mpad = gen->mpad;
+        g.tilemap = gen->tilemap;
+        g.nt128 = gen->nt128;
+    }
+    a.nt = nt;
+    a.batch = batch;
+    a.T = T;
+    a.sT = sT;
+    a.part = part;
+    a.info = info;
+#ifdef SF_TUNING
+    if (SF_TUNE_FLAG("SF_DF_VERBOSE")) a.dbg = (long long*)(flags + ((nflags - 2 * 10 * SF_CHIP_WGS - 8 + 1) & ~(size_t)1));
+#endif
+
+    // ---- the task tables: one per queue size (ceil and floor of batch / 8)
+    static const int cap = SF_TUNE_INT("SF_DF_CAP", SF_CHIP_WGS / SF_DF_QUEUES);  // workgroup slots of one XCD
+    const int kpb = GT / GK;
+    const int st_cap = (int)std::min<size_t>(SF_SPLIT_MAX, std::max<size_t>(1, sf_split_region_tiles() / (2 * (size_t)batch)));
+    a.pt_cap = st_cap;
+    a.bq[0] = (batch + SF_DF_QUEUES - 1) / SF_DF_QUEUES;
+    a.bq[1] = batch / SF_DF_QUEUES;
+    for (int v = 0; v < 2; ++v) {
+        const int B = a.bq[v];
+        if (B <= 0 || (v == 1 && a.bq[1] == a.bq[0])) {
+            a.ntasks[v] = v == 1 ? a.ntasks[0] : 0;
+            continue;
+        }
+        int off = B, thr_pt[2] = {0, 0}, thr_rp = 0, last_split[2] = {-1, -1};
+        for (int k = 0; k + 1 < nt; ++k) {
+            sf_df_stage& st = a.st[v][k];
+            const int nrest = nt - k - 2;
+            st.off = off;
+            // PT(., k+1, .): K slabs [fp / GK, k 8) of panel k+1 (everything left of panel k)
+            const int cnt_pt = (k + 2 <= nt - 1) ? k * kpb - fp / GK : 0;
+            st.St = cnt_pt >= 8 ? sf_df_split(B, cnt_pt, st_cap, cap) : 0;
+            thr_pt[(k + 1) & 1] += st.St;
+            st.thr_pt = thr_pt[(k + 1) & 1];
+            const int nk = (k * GT > fp ? k * GT - fp : 0) / GK;
+            st.Sr = nrest > 0 ? sf_df_split((long long)B * nrest, nk, SF_SPLIT_MAX, cap) : 1;
+            while (st.Sr > 1 && (size_t)B * nrest * st.Sr > SF_DF_QTILES) st.Sr /= 2;
+            st.dep = -1;
+            if (st.Sr > 1) {
+                thr_rp += st.Sr;
+                st.dep = last_split[k & 1];
+                last_split[k & 1] = k;
+            }
+            st.thr_rp = thr_rp;
+            off += B * st.St + B * nrest * (st.Sr > 1 ? st.Sr + 1 : 1) + B;
+        }
+        a.ntasks[v] = off;
+    }
+    if (a.bq[1] == a.bq[0])
+        for (int k = 0; k + 1 < nt; ++k) a.st[1][k] = a.st[0][k];
+    // algorithmic flops (as the launch sequences count them): update, solve, diagonal-tile update of every panel
+    double flops = 0.0;
+    for (int k = 0; k + 1 < nt; ++k) {
+        const int k0 = k * GT, pw = std::min(GT, n - k0);
+        const double rows = (double)(n - (k + 1) * GT);
+        flops += (2.0 * (k0 > fp ? k0 - fp : 0) * rows * pw + rows * pw * (double)pw + (double)GT * rows * pw) * batch;
+    }
+    long long total = 0;
+    for (int qx = 0; qx < SF_DF_QUEUES; ++qx) {
+        const int B = (batch - qx + SF_DF_QUEUES - 1) / SF_DF_QUEUES;
+        if (B > 0) total += a.ntasks[B == a.bq[0] ? 0 : 1];
+    }
+    static const int grid_env = SF_TUNE_INT("SF_DF_GRID", SF_CHIP_WGS);
+    const int grid = (int)std::min<long long>(total, grid_env);
+#ifdef SF_TUNING
+    if (SF_TUNE_FLAG("SF_DF_VERBOSE")) {
+        int occ = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_potrf_dataflow<false>, 512, SF_DF_LDS_BYTES);
+        fprintf(stderr, "dataflow: n=%d nt=%d batch=%d tasks=%lld grid=%d occupancy=%d/CU lds=%zu bq=%d/%d St/Sr:", n, nt, batch, total, grid,
+                occ, (size_t)SF_DF_LDS_BYTES, a.bq[0], a.bq[1]);
+        for (int k = 0; k + 1 < nt; ++k) fprintf(stderr, " %d/%d", a.st[0][k].St, a.st[0][k].Sr);
+        fprintf(stderr, "\n");
+    }
+#endif
+    void* tok;
+    sf_prof_gemm_begin(s, flops, &tok);
+    if (rhs)
+        hipLaunchKernelGGL(k_potrf_dataflow<true>, dim3(grid), dim3(512), SF_DF_LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL(k_potrf_dataflow<false>, dim3(grid), dim3(512), SF_DF_LDS_BYTES, s, a);
+    sf_prof_gemm_end(tok);
+    SF_LAUNCH_CHECK();
+#ifdef SF_TUNING
+    if (a.dbg) {
+        static long long host[10 * SF_CHIP_WGS];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(host, a.dbg, sizeof(host), hipMemcpyDeviceToHost);
+        double w = 0, bd = 0, nn = 0, ty[5] = {0, 0, 0, 0, 0};
+        long long wmax = 0, bmax = 0;
+        for (int i = 0; i < grid; ++i) {
+            w += host[8 * i];
+            bd += host[8 * i + 1];
+            nn += host[8 * i + 2];
+            for (int j = 0; j < 5; ++j) ty[j] += host[8 * i + 3 + j];
+            wmax = std::max(wmax, host[8 * i]);
+            bmax = std::max(bmax, host[8 * i] + host[8 * i + 1]);
+        }
+        int hist[16] = {0};
+        for (int i = 0; i < grid; ++i) hist[(host[8 * i + 7] - 1) & 15]++;
+        fprintf(stderr, "dataflow xcc histogram:");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %d", hist[i]);
+        fprintf(stderr, " | raw of wg 0..3: %llx %llx %llx %llx\n", host[7], host[15], host[23], host[31]);
+        fprintf(stderr, "dataflow R tasks, us per task / us per K slab by stage:");
+        for (int k = 0; k + 2 < nt; ++k) {
+            const long long* e = host + 8 * SF_CHIP_WGS + 2 * k;
+            if (e[1]) fprintf(stderr, " %d:%.0f/%.2f", k, e[0] / 100.0 / e[1], k ? e[0] / 100.0 / e[1] / (8.0 * k) : 0.0);
+        }
+        fprintf(stderr, "\n");
+        fprintf(stderr, "dataflow per workgroup: waiting %.2f ms (max %.2f), bodies %.2f ms, busy max %.2f ms, %.0f tasks; by type C %.2f PT %.2f R %.2f RP %.2f RR %.2f ms\n",
+                w / grid / 1e5, wmax / 1e5, bd / grid / 1e5, bmax / 1e5, nn / grid, ty[0] / grid / 1e5, ty[1] / grid / 1e5, ty[2] / grid / 1e5,
+                ty[3] / grid / 1e5, ty[4] / grid / 1e5);
+    }
+#endif
+    return SF_OK;
+}
+
 // Small batches are bound by the number of sequential long-K steps; the unfused sequence has half as many (256-column
 // panels).  Measured at N = 4096, fused (partial sums of top(k) beside D(k), chain at raised wave priority) / unfused:
 // B = 12: 10.0 / 9.05-9.6 ms, 16: 10.97 / 11.1, 20: 12.2 / 12.6, 24: 13.3 / 13.9, 32: 15.4 / 16.9, 64: 26.1 / 29.5.
@@ -2893,6 +3556,7 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     const int fp = gen ? gen->fp : sf_potrf_front_pad(n, batch);
     if (v3 || v3h)
         return sf_launch_potrf_v3(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex, v3h ? -2 : (sel == 2 ? -1 : tail_env), fp);
+    if (sel == 4) return sf_launch_potrf_v4(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, fp);
     if (v1 && fp == 0) return sf_launch_potrf_v1(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
     return sf_launch_potrf_v2(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex, fp);
 }

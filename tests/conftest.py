@@ -40,13 +40,13 @@ def golden():
     return load_golden
 
 
-@pytest.fixture(params=["fused", "unfused", "wide", "wide_then_narrow"])
+@pytest.fixture(params=["fused", "unfused", "wide", "wide_then_narrow", "dataflow"])
 def chol_sequence(request):
     """Runs a test under both launch sequences of the batched Cholesky (by default the library picks by batch size,
     which would leave the fused panel kernel -- the bench path -- untested at the small batches of the tests)."""
     from starfish_amd import _lib
 
     lib = _lib.require_gpu()
-    assert lib.sf_debug_cholesky_sequence({"fused": 0, "unfused": 1, "wide": 2, "wide_then_narrow": 3}[request.param]) == 0
+    assert lib.sf_debug_cholesky_sequence({"fused": 0, "unfused": 1, "wide": 2, "wide_then_narrow": 3, "dataflow": 4}[request.param]) == 0
     yield request.param
     lib.sf_debug_cholesky_sequence(-1)
