@@ -3038,6 +3038,8 @@ struct sf_df_stage {
     int thr_pt;   // PT(b, k+1, .) arrivals C(b, k+2) waits for (cumulative over the stages of the same parity)
     int thr_rp;   // RP(b, i, k, .) arrivals RR(b, i, k) waits for (cumulative)
     int dep;      // RP of this stage re-uses the partial-sum region of stage `dep` (same parity, split): wait for its reduces
+    int ndep;     // ... of which there are ndep
+    int Sl;       // while the rest tasks are unsplit: split of the two LEAD slabs k+2, k+3 (the rows the chain needs next), 0 = none
 };
 template <class S>
 __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy out of the constant address space)
@@ -3048,6 +3050,8 @@ __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy
     r.thr_pt = x.thr_pt;
     r.thr_rp = x.thr_rp;
     r.dep = x.dep;
+    r.ndep = x.ndep;
+    r.Sl = x.Sl;
     return r;
 }
 // One task queue per XCD: matrix b belongs to queue b % 8 (its slabs share the B operand L[panel rows, :k0] through that
@@ -3055,14 +3059,15 @@ __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy
 // HBM reads, 66 ms instead of 50 for 128 matrices); a workgroup serves the queue of the XCD it runs on and, once that is
 // exhausted, the others in turn.  Queues with the same number of matrices share a task table (at most two sizes).
 #define SF_DF_QUEUES 8
-#define SF_DF_MAX_STAGES 64
+#define SF_DF_MAX_STAGES 48  // (two tables of 32-byte entries in the kernel arguments: < 4 KB)
 #define SF_DF_QTILES (2 * SF_CHIP_WGS / SF_DF_QUEUES)  // partial-sum tiles per queue and stage parity
 struct sf_df_args {
     sf_panel_args p;  // matrix, right-hand side, generator, frame: the per-task fields are filled in by the kernel
     int nt, batch;
     int bq[2], ntasks[2];  // table v serves the queues with bq[v] matrices
     int pt_cap;       // largest split of the chain's partial sums: a matrix owns pt_cap tiles per panel parity in region 2
-    int *head, *abort_flag, *done_top, *done_D, *done_row, *pt_cnt, *rp_cnt, *stage_done;
+    int *head, *abort_flag, *done_top, *done_D, *done_row, *pt_cnt, *rp_cnt, *lp_cnt, *stage_done;
+    int* chain_next;  // [batch]: the next chain task of every matrix (claimed by compare-and-swap once it is ready)
     double* T;        // per matrix: parked diagonal tile [GT x SF_LDT], then W_k for every panel
     int64_t sT;
     double* part;     // three regions of sf_split_region_tiles() tiles: rest partial sums by stage parity, chain partial sums
@@ -3102,22 +3107,76 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
         const int B = (a.batch - qcur + SF_DF_QUEUES - 1) / SF_DF_QUEUES;  // matrices of this queue: qcur, qcur + 8, ...
         const int v = B == a.bq[0] ? 0 : 1;
         const int ntasks = B > 0 ? a.ntasks[v] : 0;
+        // ---- dispenser.  Chain tasks first: they are not in the queues but claimed, per matrix and in order, by whichever
+        // workgroup finds one READY (its first-half dependencies met) -- in the queue a chain task waited until some workgroup
+        // had worked its way to it (150 us behind long rest tasks in the timeline of 16 matrices), and a task claimed before
+        // it is ready would only hold a workgroup spinning.  Then the queue of this workgroup's XCD, then the other queues.
         if (tid == 0) {
-            int t = -1;
-            if (sf_df_load(a.abort_flag) == 0)
-                t = ntasks > 0 ? __hip_atomic_fetch_add(a.head + qcur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ntasks;
+            int t = -1, cb = 0, ck = 0;
+            if (sf_df_load(a.abort_flag) == 0) {
+                t = -2;
+                auto try_chain = [&](int qx) {  // a ready chain task among the matrices of queue qx?
+                    const int Bq = (a.batch - qx + SF_DF_QUEUES - 1) / SF_DF_QUEUES;
+                    const int vq = Bq == a.bq[0] ? 0 : 1;
+                    for (int j = 0; j < Bq; ++j) {
+                        const int b1 = qx + SF_DF_QUEUES * j;
+                        const int k1 = sf_df_load(a.chain_next + b1);
+                        if (k1 >= nt) continue;
+                        bool ready = true;
+                        if (k1 >= 1) {
+                            const int kp = k1 - 1;
+                            ready = sf_df_load(a.done_top + b1) >= kp;
+                            if (ready && kp >= 1) {
+                                ready = sf_df_load(a.done_row + (size_t)b1 * nt + k1) >= kp;
+                                const int St = a.st[vq][kp - 1].St;
+                                if (ready && St > 0) ready = sf_df_load(a.pt_cnt + 2 * b1 + (kp & 1)) >= a.st[vq][kp - 1].thr_pt;
+                            }
+                        }
+                        if (!ready) continue;
+                        int expect = k1;
+                        if (__hip_atomic_compare_exchange_strong(a.chain_next + b1, &expect, k1 + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+                            cb = b1;
+                            ck = k1;
+                            return true;
+                        }
+                    }
+                    return false;
+                };
+                if (try_chain(qcur)) {
+                    t = -3;
+                } else if (visited < SF_DF_QUEUES) {
+                    t = ntasks > 0 ? __hip_atomic_fetch_add(a.head + qcur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ntasks;
+                    if (t >= ntasks) t = -4;  // this queue is exhausted
+                } else {
+                    // every queue is exhausted: help the chains that are still running, leave when none is
+                    bool live = false;
+                    for (int qx = 0; qx < SF_DF_QUEUES && t == -2; ++qx)
+                        if (try_chain(qx)) t = -3;
+                    if (t == -2) {
+                        for (int b1 = 0; b1 < a.batch; ++b1) live = live || sf_df_load(a.chain_next + b1) < nt;
+                        if (!live) t = -5;
+                        else __builtin_amdgcn_s_sleep(64);
+                    }
+                }
+            }
             s_ints[0] = t;
+            s_ints[2] = cb;
+            s_ints[3] = ck;
         }
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(s_ints[0]);  // (wave-uniform: everything decoded from it lives in SGPRs)
+        const int chain_b = __builtin_amdgcn_readfirstlane(s_ints[2]), chain_k = __builtin_amdgcn_readfirstlane(s_ints[3]);
         __syncthreads();
-        if (t < 0) {  // a wait timed out somewhere: nothing of this launch can be trusted
+        if (t == -1) {  // a wait timed out somewhere: nothing of this launch can be trusted
             if (a.info)
                 for (int bb = tid; bb < a.batch; bb += 512) a.info[bb] = SF_INFO_INTERNAL;
             return;
         }
-        if (t >= ntasks) {  // this queue is exhausted: the next one
-            if (++visited == SF_DF_QUEUES) return;
+        if (t == -5) return;
+        if (t == -2) continue;
+        if (t == -4) {  // this queue is exhausted: the next one
+            ++visited;
             qcur = (qcur + 1) & (SF_DF_QUEUES - 1);
             kst = 0;
             continue;
@@ -3125,7 +3184,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
 
         // ---- decode
         enum { T_C, T_PT, T_R, T_RP, T_RR };
-        int type, bl, k, i = 0, sp = 0, S = 1;
+        int type, bl, k, i = 0, sp = 0, S = 1, lead = 0;
         // rest tile -> (slab, matrix): the two slabs the chain needs next come first, for every matrix; the others matrix by
         // matrix, so that the tasks running side by side on an XCD stream the SAME B operand L[panel rows, :k0] more or
         // less in step (slab-major order: 16 matrices x 2 MB of B operand in flight per XCD -- nothing of it survives in the L2)
@@ -3140,17 +3199,27 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 i = kk + 2 + lead + (u2 - bl * per);
             }
         };
-        if (t < B) {
+        int bchain = -1;
+        if (t == -3) {
             type = T_C;
-            bl = t;
-            k = 0;
+            bchain = chain_b;
+            bl = 0;
+            k = chain_k;
         } else {
             while (kst + 1 < nt - 1 && t >= a.st[v][kst + 1].off) ++kst;
             const sf_df_stage st = sf_df_stage_of(a.st[v][kst]);
             const int nrest = nt - kst - 2;
             const int n_pt = B * st.St;
-            const int n_r = B * nrest;
+            // lead slabs (only while the rest tasks are unsplit): their partial sums and reduces come first
+            const int nl = st.Sl > 0 ? min(nrest, 2) : 0;
+            const int n_lp = B * nl * st.Sl, n_lr = B * nl;
+            const int n_r = B * (nrest - nl);
             const int n_r1 = st.Sr > 1 ? n_r * st.Sr : (n_r + 1) / 2;
+            auto plain_tile = [&](int tile) {  // the slabs behind the lead slabs, matrix by matrix
+                const int per = nrest - nl;
+                bl = tile / per;
+                i = kst + 2 + nl + (tile - bl * per);
+            };
             int u = t - st.off;
             if (u < n_pt) {
                 type = T_PT;
@@ -3158,7 +3227,23 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 S = st.St;
                 bl = u / S;
                 sp = u - bl * S;
-            } else if ((u -= n_pt) < n_r1) {
+            } else if ((u -= n_pt) < n_lp) {
+                type = T_RP;
+                lead = 1;
+                k = kst;
+                S = st.Sl;
+                const int tile = u / S;
+                sp = u - tile * S;
+                i = k + 2 + tile / B;
+                bl = tile % B;
+            } else if ((u -= n_lp) < n_lr) {
+                type = T_RR;
+                lead = 1;
+                k = kst;
+                S = st.Sl;
+                i = k + 2 + u / B;
+                bl = u % B;
+            } else if ((u -= n_lr) < n_r1) {
                 k = kst;
                 if (st.Sr > 1) {
                     type = T_RP;
@@ -3168,30 +3253,31 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     rest_tile(tile, k, nrest);
                 } else {
                     type = T_R;
-                    rest_tile(u, k, nrest);
+                    if (nl) plain_tile(u);
+                    else rest_tile(u, k, nrest);
                 }
-            } else if ((u -= n_r1) < B) {
-                type = T_C;
-                bl = u;
-                k = kst + 1;
             } else {
-                u -= B;
+                u -= n_r1;
                 k = kst;
                 type = st.Sr > 1 ? T_RR : T_R;
                 S = st.Sr;
-                rest_tile(st.Sr > 1 ? u : n_r1 + u, k, nrest);
+                if (st.Sr > 1) rest_tile(u, k, nrest);
+                else if (nl) plain_tile(n_r1 + u);
+                else rest_tile(n_r1 + u, k, nrest);
             }
         }
+        lead = __builtin_amdgcn_readfirstlane(lead);
         bl = __builtin_amdgcn_readfirstlane(bl);  // (the divisions above ran on the VALU)
         i = __builtin_amdgcn_readfirstlane(i);
         sp = __builtin_amdgcn_readfirstlane(sp);
         k = __builtin_amdgcn_readfirstlane(k);
         S = __builtin_amdgcn_readfirstlane(S);
         type = __builtin_amdgcn_readfirstlane(type);
-        const int b = qcur + SF_DF_QUEUES * bl;  // the matrix
+        const int b = bchain >= 0 ? bchain : qcur + SF_DF_QUEUES * bl;  // the matrix
+        const int vb = bchain >= 0 ? (((a.batch - (b & (SF_DF_QUEUES - 1)) + SF_DF_QUEUES - 1) / SF_DF_QUEUES) == a.bq[0] ? 0 : 1) : v;  // its queue's table
 #ifdef SF_TUNING
         const long long dbg_t0 = wall_clock64();
-        long long dbg_t1 = dbg_t0;
+        long long dbg_t1 = dbg_t0, dbg_top = 0;
 #define SF_DF_MARK() dbg_t1 = wall_clock64()
 #else
 #define SF_DF_MARK()
@@ -3208,6 +3294,8 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
         auto Wof = [&](int kk) { return a.T + (size_t)(1 + kk) * GT * SF_LDT; };
         bool ok = true;
         if (type == T_C) {
+            // the chain's waves share their SIMDs with rest tasks issuing MFMAs back to back
+            __builtin_amdgcn_s_setprio(2);
             q.Sout = a.T;  // (g.sS = a.sT, g.ldS = SF_LDT)
             if (k == 0) {
                 // start of the factorisation: diagonal tile 0 goes to the scratch unchanged (pw = 0)
@@ -3216,7 +3304,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
             } else {
                 const int kp = k - 1;  // the step of slab k for panel kp
-                const sf_df_stage stp = sf_df_stage_of(a.st[v][kp > 0 ? kp - 1 : 0]);  // (PT(., kp, .) belongs to stage kp - 1)
+                const sf_df_stage stp = sf_df_stage_of(a.st[vb][kp > 0 ? kp - 1 : 0]);  // (PT(., kp, .) belongs to stage kp - 1)
                 const int St = kp >= 1 ? stp.St : 0;
                 q.k0 = kp * GT;
                 q.pw = min(GT, n - q.k0);
@@ -3226,13 +3314,24 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 q.ktail = St > 0 ? (kp - 1) * (GT / GK) : 0;
                 q.part = a.part + 2 * region + ((size_t)(kp & 1) * a.batch * a.pt_cap + (size_t)b * (a.pt_cap - St)) * (GT * GT);
                 // row k left of the tail (rest task of stage kp - 1), the previous chain task (row kp, W_kp), the partial sums
-                ok = sf_df_wait(kp >= 1 ? a.done_row + (size_t)b * nt + k : nullptr, kp, a.done_D + b, kp + 1,
-                                St > 0 ? a.pt_cnt + 2 * b + (kp & 1) : nullptr, stp.thr_pt, nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
+                // (partial sums + K tail need row kp final = the FIRST half of the previous chain task; only the solve needs its
+                // second half, the diagonal tile D(kp): this task's K work runs beside D(kp), in another workgroup)
+                bool dready = false;
+                ok = sf_df_wait(kp >= 1 ? a.done_row + (size_t)b * nt + k : nullptr, kp, a.done_top + b, kp,
+                                St > 0 ? a.pt_cnt + 2 * b + (kp & 1) : nullptr, stp.thr_pt, a.done_D + b, kp + 1, &dready, a.abort_flag,
+                                tid, s_ints + 1);
+                if (!dready) {
+                    q.wflag = a.done_D + b;
+                    q.wval = kp + 1;
+                }
                 SF_DF_MARK();
                 if (ok) sf_panel_body<RHS, 3>(g, q, b, sm, red, tid);
             }
             if (ok) {
                 __syncthreads();
+#ifdef SF_TUNING
+                dbg_top = wall_clock64();
+#endif
                 if (tid == 0) {  // row k is final through panel k-1; the parked tile must be re-read through the L2
                     sf_df_release();
                     sf_df_set(a.done_top + b, k);
@@ -3249,6 +3348,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     sf_df_set(a.done_D + b, k + 1);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         } else {
             const int k0 = k * GT;
             const int nk = (k0 > fp ? k0 - fp : 0) / GK;
@@ -3298,12 +3398,15 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     if (ok) sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
                 } else if (type == T_RP) {
                     ok = sf_df_wait(k >= 1 ? a.done_top + b : nullptr, k, rowflag, k, st.dep >= 0 ? sdone + st.dep : nullptr,
-                                    B * (nt - st.dep - 2), nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
+                                    st.ndep, nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
                     SF_DF_MARK();
                     if (ok) sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
                 } else {
-                    ok = sf_df_wait(a.rp_cnt + (size_t)b * nt + i, st.thr_rp, a.done_D + b, k + 1, nullptr, 0, nullptr, 0, nullptr,
-                                    a.abort_flag, tid, s_ints + 1);
+                    // (a lead slab's partial-sum counter is cumulative over the two stages in which the slab leads)
+                    int thr = st.thr_rp;
+                    if (lead) thr = st.Sl + ((i == k + 2 && k >= 1) ? a.st[v][k - 1].Sl : 0);
+                    ok = sf_df_wait((lead ? a.lp_cnt : a.rp_cnt) + (size_t)b * nt + i, thr, a.done_D + b, k + 1, nullptr, 0, nullptr, 0,
+                                    nullptr, a.abort_flag, tid, s_ints + 1);
                     SF_DF_MARK();
                     if (ok) sf_panel_body<RHS, 2>(g, q, b, sm, red, tid);
                 }
@@ -3312,7 +3415,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 if (ok && tid == 0) {
                     sf_df_release();
                     if (type == T_RP) {
-                        sf_df_add(a.rp_cnt + (size_t)b * nt + i, 1);
+                        sf_df_add((lead ? a.lp_cnt : a.rp_cnt) + (size_t)b * nt + i, 1);
                     } else {
                         sf_df_set(rowflag, k + 1);
                         if (type == T_RR) sf_df_add(sdone + k, 1);
@@ -3330,6 +3433,16 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
             d[1] += t2 - dbg_t1;
             d[2] += 1;
             d[7] = 1 + (long long)(xcc & 0xffff) + ((long long)qcur << 16) + ((long long)visited << 24);
+            if (b == 0 && k < 64) {  // timeline of matrix 0: chain task, its partial sums, the lead slab's tasks
+                long long* tr = a.dbg + 10 * SF_CHIP_WGS + 16 * k;
+                const int slot = type == T_C ? 0 : (type == T_PT && sp == 0) ? 3 : (i == k + 2 && sp == 0 && type != T_RR) ? 6 : (i == k + 2 && type == T_RR) ? 9 : -1;
+                if (slot >= 0) {
+                    tr[slot] = dbg_t0;
+                    tr[slot + 1] = dbg_t1;
+                    tr[slot + 2] = t2;
+                    if (type == T_C) tr[12] = dbg_top;
+                }
+            }
             if (type == T_R) {  // per-stage totals of the unsplit rest tasks (body only, waits excluded)
                 atomicAdd((unsigned long long*)(a.dbg + 8 * SF_CHIP_WGS + 2 * k), (unsigned long long)(t2 - dbg_t1));
                 atomicAdd((unsigned long long*)(a.dbg + 8 * SF_CHIP_WGS + 2 * k + 1), 1ull);
@@ -3369,7 +3482,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     const int nt = (n + GT - 1) / GT;
     // counters: in the two inverse-tile buffers of the launch sequences (2 x batch x sW doubles), which this sequence does not use
     int* flags = (int*)Wt2;
-    const size_t nflags = 64 + (size_t)batch * (2 * nt + 4) + (size_t)SF_DF_QUEUES * nt + 2 * 10 * SF_CHIP_WGS + 8;
+    const size_t nflags = 64 + (size_t)batch * (3 * nt + 5) + (size_t)SF_DF_QUEUES * nt + 2 * 10 * SF_CHIP_WGS + 8 + 2 * 16 * 64;
     if (nt - 1 > SF_DF_MAX_STAGES || nflags * sizeof(int) > 2 * (size_t)batch * sW * sizeof(double)) {
         sf_set_error("potrf: dataflow sequence: %d panels / %d matrices do not fit its tables", nt, batch);
         return SF_EINVAL;
@@ -3382,7 +3495,9 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.pt_cnt = a.done_D + batch;            // [batch][2]
     a.done_row = a.pt_cnt + 2 * batch;      // [batch][nt]
     a.rp_cnt = a.done_row + (size_t)batch * nt;
-    a.stage_done = a.rp_cnt + (size_t)batch * nt;  // [SF_DF_QUEUES][nt]
+    a.lp_cnt = a.rp_cnt + (size_t)batch * nt;
+    a.stage_done = a.lp_cnt + (size_t)batch * nt;  // [SF_DF_QUEUES][nt]
+    a.chain_next = a.stage_done + (size_t)SF_DF_QUEUES * nt;
     SF_HIP(hipMemsetAsync(flags, 0, nflags * sizeof(int), s));
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
 
@@ -3415,11 +3530,12 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.part = part;
     a.info = info;
 #ifdef SF_TUNING
-    if (SF_TUNE_FLAG("SF_DF_VERBOSE")) a.dbg = (long long*)(flags + ((nflags - 2 * 10 * SF_CHIP_WGS - 8 + 1) & ~(size_t)1));
+    if (SF_TUNE_FLAG("SF_DF_VERBOSE")) a.dbg = (long long*)(flags + ((nflags - 2 * 10 * SF_CHIP_WGS - 8 - 2 * 16 * 64 + 1) & ~(size_t)1));
 #endif
 
     // ---- the task tables: one per queue size (ceil and floor of batch / 8)
     static const int cap = SF_TUNE_INT("SF_DF_CAP", SF_CHIP_WGS / SF_DF_QUEUES);  // workgroup slots of one XCD
+    static const int lead_bq = SF_TUNE_INT("SF_DF_LEAD_BQ", 0);  // lead slabs are split for queues of up to this many matrices
     const int kpb = GT / GK;
     const int st_cap = (int)std::min<size_t>(SF_SPLIT_MAX, std::max<size_t>(1, sf_split_region_tiles() / (2 * (size_t)batch)));
     a.pt_cap = st_cap;
@@ -3431,7 +3547,8 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
             a.ntasks[v] = v == 1 ? a.ntasks[0] : 0;
             continue;
         }
-        int off = B, thr_pt[2] = {0, 0}, thr_rp = 0, last_split[2] = {-1, -1};
+        int off = 0, thr_pt[2] = {0, 0}, thr_rp = 0, last_split[2] = {-1, -1};
+        int nred_of[SF_DF_MAX_STAGES + 1] = {0};
         for (int k = 0; k + 1 < nt; ++k) {
             sf_df_stage& st = a.st[v][k];
             const int nrest = nt - k - 2;
@@ -3444,14 +3561,28 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
             const int nk = (k * GT > fp ? k * GT - fp : 0) / GK;
             st.Sr = nrest > 0 ? sf_df_split((long long)B * nrest, nk, SF_SPLIT_MAX, cap) : 1;
             while (st.Sr > 1 && (size_t)B * nrest * st.Sr > SF_DF_QTILES) st.Sr /= 2;
+            // lead slabs: while the chain is what the rest waits for (few matrices per queue), the two slabs it needs next
+            // are split even when the stage as a whole is not
+            st.Sl = 0;
+            const int nl = std::min(nrest, 2);
+            if (st.Sr == 1 && nl > 0 && B <= lead_bq) {
+                st.Sl = sf_df_split((long long)B * nl, nk, SF_SPLIT_MAX, cap);
+                while (st.Sl > 1 && (size_t)B * nl * st.Sl > SF_DF_QTILES) st.Sl /= 2;
+                if (st.Sl < 2) st.Sl = 0;
+            }
             st.dep = -1;
-            if (st.Sr > 1) {
-                thr_rp += st.Sr;
+            st.ndep = 0;
+            const int nred = st.Sr > 1 ? B * nrest : (st.Sl > 0 ? B * nl : 0);  // reduce tasks of this stage
+            if (st.Sr > 1) thr_rp += st.Sr;
+            if (nred > 0) {
                 st.dep = last_split[k & 1];
+                st.ndep = st.dep >= 0 ? nred_of[st.dep] : 0;
                 last_split[k & 1] = k;
             }
+            nred_of[k] = nred;
             st.thr_rp = thr_rp;
-            off += B * st.St + B * nrest * (st.Sr > 1 ? st.Sr + 1 : 1) + B;
+            off += B * st.St + (st.Sl > 0 ? B * nl * (st.Sl + 1) : 0) +
+                   B * (nrest - (st.Sl > 0 ? nl : 0)) * (st.Sr > 1 ? st.Sr + 1 : 1);
         }
         a.ntasks[v] = off;
     }
@@ -3470,6 +3601,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
         if (B > 0) total += a.ntasks[B == a.bq[0] ? 0 : 1];
     }
     static const int grid_env = SF_TUNE_INT("SF_DF_GRID", SF_CHIP_WGS);
+    total += (long long)batch * nt;  // (+ the chain tasks)
     const int grid = (int)std::min<long long>(total, grid_env);
 #ifdef SF_TUNING
     if (SF_TUNE_FLAG("SF_DF_VERBOSE")) {
@@ -3477,7 +3609,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_potrf_dataflow<false>, 512, SF_DF_LDS_BYTES);
         fprintf(stderr, "dataflow: n=%d nt=%d batch=%d tasks=%lld grid=%d occupancy=%d/CU lds=%zu bq=%d/%d St/Sr:", n, nt, batch, total, grid,
                 occ, (size_t)SF_DF_LDS_BYTES, a.bq[0], a.bq[1]);
-        for (int k = 0; k + 1 < nt; ++k) fprintf(stderr, " %d/%d", a.st[0][k].St, a.st[0][k].Sr);
+        for (int k = 0; k + 1 < nt; ++k) fprintf(stderr, " %d/%d/%d", a.st[0][k].St, a.st[0][k].Sr, a.st[0][k].Sl);
         fprintf(stderr, "\n");
     }
 #endif
@@ -3491,7 +3623,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     SF_LAUNCH_CHECK();
 #ifdef SF_TUNING
     if (a.dbg) {
-        static long long host[10 * SF_CHIP_WGS];
+        static long long host[10 * SF_CHIP_WGS + 16 * 64];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(host, a.dbg, sizeof(host), hipMemcpyDeviceToHost);
         double w = 0, bd = 0, nn = 0, ty[5] = {0, 0, 0, 0, 0};
@@ -3515,6 +3647,17 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
             if (e[1]) fprintf(stderr, " %d:%.0f/%.2f", k, e[0] / 100.0 / e[1], k ? e[0] / 100.0 / e[1] / (8.0 * k) : 0.0);
         }
         fprintf(stderr, "\n");
+        if (SF_TUNE_FLAG("SF_DF_TRACE")) {
+            const long long* tr = host + 10 * SF_CHIP_WGS;
+            long long t0 = tr[0];
+            fprintf(stderr, "matrix 0, us since its first task: k | C claim start end | PT(k) claim start end | lead R(k+2,k) claim start end | lead RR claim start end\n");
+            for (int k = 0; k < nt && k < 64; ++k) {
+                fprintf(stderr, "%2d |", k);
+                for (int j = 0; j < 12; ++j) fprintf(stderr, "%s%8.1f", j % 3 == 0 && j ? " |" : "", tr[16 * k + j] ? (tr[16 * k + j] - t0) / 100.0 : 0.0);
+                fprintf(stderr, " | C: panel part %6.1f, D %6.1f", (tr[16 * k + 12] - tr[16 * k + 1]) / 100.0, (tr[16 * k + 2] - tr[16 * k + 12]) / 100.0);
+                fprintf(stderr, "\n");
+            }
+        }
         fprintf(stderr, "dataflow per workgroup: waiting %.2f ms (max %.2f), bodies %.2f ms, busy max %.2f ms, %.0f tasks; by type C %.2f PT %.2f R %.2f RP %.2f RR %.2f ms\n",
                 w / grid / 1e5, wmax / 1e5, bd / grid / 1e5, bmax / 1e5, nn / grid, ty[0] / grid / 1e5, ty[1] / grid / 1e5, ty[2] / grid / 1e5,
                 ty[3] / grid / 1e5, ty[4] / grid / 1e5);
