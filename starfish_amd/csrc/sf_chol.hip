@@ -3670,11 +3670,24 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
 // panels).  Measured at N = 4096, fused (partial sums of top(k) beside D(k), chain at raised wave priority) / unfused:
 // B = 12: 10.0 / 9.05-9.6 ms, 16: 10.97 / 11.1, 20: 12.2 / 12.6, 24: 13.3 / 13.9, 32: 15.4 / 16.9, 64: 26.1 / 29.5.
 #define SF_UNFUSED_BELOW 16
+// The dataflow sequence (one persistent launch) wins wherever the launch sequences cannot keep the chip full between their
+// panel boundaries.  Measured (tools/bench_potrf.py, same box, launch sequences / dataflow): N = 4096: B = 4 6.5 / 6.0 ms,
+// 8: 7.4 / 6.4, 12: 8.8 / 8.5, 16: 10.3 / 8.7, 24: 12.7 / 12.1, 32: 15.0 / 14.7, 48: 20.7 / 20.7, 64: 26.0 / 26.5, 128: 49.3
+// (wide: 47.0) / 51.1; N = 3008: B = 16 6.15 / 4.74, 64: 11.8 / 12.3; N = 2048: B = 16 3.36 / 2.50, 64: 5.22 / 5.02;
+// N = 1024: B = 16 1.29 / 0.88, 64: 1.51 / 1.40  ->  taken while batch x panels <= 1280.
+static bool sf_potrf_dataflow_auto(int n, int batch) {
+    static const int lim = SF_TUNE_INT("SF_DF_BELOW", 1280);
+    const int nt = (n + 64 + GT - 1) / GT;  // (panels of the shifted frame at most)
+    return nt - 1 <= SF_DF_MAX_STAGES && (long long)batch * nt <= lim;
+}
 int sf_potrf_front_pad(int n, int batch) {
     static const bool off = SF_TUNE_FLAG("SF_NO_FRONT_PAD");  // tuning aid: A/B of the shifted frame
     static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");
     const int sel = g_chol_sequence.load();
-    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < SF_UNFUSED_BELOW);  // (as in sf_launch_potrf)
+    // (a matrix with more panels than the dataflow tables hold takes the fused sequence when the dataflow one is forced)
+    const bool df_fits = (n + 64 + GT - 1) / GT - 1 <= SF_DF_MAX_STAGES;
+    const bool df = sel >= 0 ? (sel == 4 && df_fits) : (!force && sf_potrf_dataflow_auto(n, batch));
+    const bool v1 = !df && (sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < SF_UNFUSED_BELOW));  // (as in sf_launch_potrf)
     if (off || v1 || n % GT != 64 || n < 2 * GT) return 0;
     return 64;
 }
@@ -3684,22 +3697,24 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     // The fused panel kernel (128-column panels) is the faster sequence once the batch fills the chip (SF_UNFUSED_BELOW).
     static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");  // tuning aid: "1" always unfused, "0" always fused
     const int sel = g_chol_sequence.load();                 // sf_debug_cholesky_sequence(): tests drive both
-    const bool v1 = sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < SF_UNFUSED_BELOW);
+    const bool df_fits = (n + 64 + GT - 1) / GT - 1 <= SF_DF_MAX_STAGES;
+    const bool df = sel >= 0 ? (sel == 4 && df_fits) : (!force && sf_potrf_dataflow_auto(n, batch));
+    const bool v1 = !df && (sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < SF_UNFUSED_BELOW));
     // The wide sequence (panel pairs, one 16-wave workgroup per CU) halves the A-operand stream and a third of all HBM
     // traffic of the factorisation, but one workgroup per CU has nothing to overlap its epilogue and barriers with: it pays
     // once its launches are many rounds of workgroups.  Measured (bench.py, same box, fused / wide): N = 4096: B = 48
     // 21.45 / 23.1 ms, 64: 27.34 / 27.4, 80: 33.0 / 33.4, 96: 38.2 / 38.6, 112: 44.6 / 43.9, 128: 49.7 / 48.4; N = 16384,
     // B = 32 (cfg 5): 707.7 / 696.6; 1600 units of N = 3008 (cfg 3): 277.3 / 273.2 -> taken from batch x slabs >= 3400.
     const bool wide_auto = n >= 2048 && (long long)batch * ((n + GT - 1) / GT) >= 3400;
-    const bool v3 = sel >= 0 ? sel == 2 : (force ? force[0] == '2' : wide_auto);
+    const bool v3 = !df && (sel >= 0 ? sel == 2 : (force ? force[0] == '2' : wide_auto));
     if (!ex) ex = sf_exec_thread_local();
     static const int tail_env = SF_TUNE_INT("SF_WIDE_TAIL_ROUNDS", -1);  // measured at cfg 2: -1 (wide to the end) 49.3 ms, 2: 50.0, 5: 50.4, 8: 51.0, 12: 51.8 (narrow: 51.5)
     const bool v3h = sel == 3;  // (test aid) wide pairs for the first half of the panels, narrow steps after
     // frame of the fused sequences: the caller's (whose tile map was built in it) or this call's own
     const int fp = gen ? gen->fp : sf_potrf_front_pad(n, batch);
+    if (df) return sf_launch_potrf_v4(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, fp);
     if (v3 || v3h)
         return sf_launch_potrf_v3(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex, v3h ? -2 : (sel == 2 ? -1 : tail_env), fp);
-    if (sel == 4) return sf_launch_potrf_v4(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, fp);
     if (v1 && fp == 0) return sf_launch_potrf_v1(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex);
     return sf_launch_potrf_v2(A, n, lda, stride, batch, info, work, rhs, ldr, s, gen, ex, fp);
 }

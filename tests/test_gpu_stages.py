@@ -86,7 +86,7 @@ def test_transform_argument_errors(gpu):
     np.testing.assert_allclose(T.instrumental_broaden(w, f, 0.0), f, atol=1e-14)
 
 
-@pytest.mark.parametrize("n,batch", [(64, 3), (256, 5), (1024, 2), (1088, 2), (1984, 3), (640, 40), (3008, 2)])
+@pytest.mark.parametrize("n,batch", [(64, 3), (192, 9), (256, 5), (1024, 2), (1088, 2), (1984, 3), (640, 40), (3008, 2), (1152, 17)])
 def test_potrf_logdet_sqmah_random_spd(gpu, chol_sequence, n, batch):
     import torch
     from starfish_amd import _device as D, _lib

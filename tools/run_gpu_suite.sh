@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3final
-(time python -m pytest tests -m gpu -x -q) > gpurun_out/r3final/tests.log 2>&1; tail -3 gpurun_out/r3final/tests.log
+O=gpurun_out/${TAG:-suite}; mkdir -p $O
+(time timeout 3000 python -m pytest tests -m gpu -x -q) > $O/tests.log 2>&1; tail -4 $O/tests.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
