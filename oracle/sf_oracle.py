@@ -472,8 +472,12 @@ def forward_model(order, p):
         scale = renorm_factor(order.wave, flux * norm, order.flux) * norm
     flux = flux * scale
     X = X * scale
-    fac = cho_factor(w_cov)
-    cov = X.T @ cho_solve(fac, X)
+    if p.get("emulator_cov", "code") == "paper":
+        # the form printed in the paper / docs (docs/api/emulator.rst:105): Phi Sigma_w Phi^T; non-default switch
+        cov = X.T @ w_cov @ X
+    else:
+        fac = cho_factor(w_cov)
+        cov = X.T @ cho_solve(fac, X)  # what the code does: spectrum_model.py:334-335
     idx = np.arange(len(order.wave))
     cov[idx, idx] += order.sigma**2
     if "global_cov" in p:

@@ -56,7 +56,7 @@ class SpectrumModel:
     _LOCAL_PARAMS = ["mu", "log_amp", "log_sigma"]
 
     def __init__(self, emulator, data, grid_params, max_deque_len=100, norm=False, name="SpectrumModel",
-                 device=None, solver="dense", **params):
+                 device=None, solver="dense", emulator_cov="code", **params):
         if isinstance(emulator, str):
             emulator = Emulator.load(emulator)
         if isinstance(data, str):
@@ -74,6 +74,12 @@ class SpectrumModel:
         if solver not in ("dense", "banded", "auto"):
             raise ValueError("solver must be 'dense', 'banded' or 'auto'")
         self.solver = solver
+        #: form of the emulator term of the covariance.  "code" (default, the parity target): X^T Sigma_w^-1 X, what the
+        #: reference COMPUTES (spectrum_model.py:334-335: cho_solve of the weight covariance); "paper": X^T Sigma_w X, the
+        #: form printed in the reference's docs (docs/api/emulator.rst:105) and in Czekala et al. (2015).
+        if emulator_cov not in ("code", "paper"):
+            raise ValueError("emulator_cov must be 'code' or 'paper'")
+        self.emulator_cov = emulator_cov
 
         dv = calculate_dv(self.data.wave)
         self.min_dv_wave = create_log_lam_grid(dv, self.emulator.wl.min(), self.emulator.wl.max())["wl"]
@@ -317,7 +323,8 @@ class SpectrumModel:
         n_cheb = len(self.params["cheb"]) if "cheb" in self.params else 0
         return dev.model_desc(
             "vsini" in self.params, "vz" in self.params, "log_scale" in self.params,
-            "global_cov" in self.params, n_local, n_cheb, has_av="Av" in self.params,
+            "global_cov" in self.params, n_local, n_cheb, use_sigma_w=self.emulator_cov == "paper",
+            has_av="Av" in self.params,
         )
 
     def _slot_of(self, dev, md):

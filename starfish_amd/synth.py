@@ -203,7 +203,7 @@ def perturb_grid(order, rng_seed=7):
     return out
 
 
-def build_model(order, params=None, device=None, solver="dense", freeze=()):
+def build_model(order, params=None, device=None, solver="dense", freeze=(), emulator_cov="code"):
     """A product ``SpectrumModel`` (own ``Emulator`` + ``Spectrum``) for a synthetic order: the path a user
     takes, including the model's own init-time resample of the emulator's bulk fluxes."""
     from . import Spectrum
@@ -216,7 +216,7 @@ def build_model(order, params=None, device=None, solver="dense", freeze=()):
     data = Spectrum(order["wave"], order["flux"], sigmas=order["sigma"])
     c = dict(centre_params(order)) if params is None else dict(params)
     gp = c.pop("grid_params")
-    model = SpectrumModel(emu, data, grid_params=gp, device=device, solver=solver, **c)
+    model = SpectrumModel(emu, data, grid_params=gp, device=device, solver=solver, emulator_cov=emulator_cov, **c)
     for name in freeze:
         model.freeze(name)
     return model

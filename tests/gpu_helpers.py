@@ -24,7 +24,7 @@ def device_order(oo):
 def model_desc(dev_order, p):
     return dev_order.model_desc(
         "vsini" in p, "vz" in p, "log_scale" in p, "global_cov" in p, len(p.get("local_cov", [])),
-        len(p.get("cheb", [])), has_av="Av" in p,
+        len(p.get("cheb", [])), use_sigma_w=p.get("emulator_cov", "code") == "paper", has_av="Av" in p,
     )
 
 

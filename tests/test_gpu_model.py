@@ -428,3 +428,35 @@ def C_byref(md):
     import ctypes
 
     return ctypes.byref(md)
+
+
+def test_paper_form_of_the_emulator_covariance_is_a_non_default_switch():
+    """the reference's CODE applies the inverse weight covariance, X^T Sigma_w^-1 X
+    (spectrum_model.py:334-335) -- the default and the parity target; its docs print Phi Sigma_w Phi^T
+    (docs/api/emulator.rst:105).  ``emulator_cov="paper"`` evaluates that form; checked against the oracle's restatement of
+    it (no reference value exists: the reference never computes it), the default against the reference golden."""
+    g = load_golden("model_small.npz")
+    o = synth.make_order(N=256, m=4, seed=5)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    base = small_params(o, "full", g["factors"])
+    pp = dict(base, emulator_cov="paper")
+    md, rows = pack_rows(do, [pp])
+    out = do.loglike(md, rows)
+    fw = do.forward(md, rows)
+    _, c_or, _ = O.forward_model(oo, pp)
+    np.testing.assert_allclose(fw["cov"][0], c_or, rtol=1e-10, atol=1e-11 * np.abs(c_or).max())
+    assert out["info"][0] == 0 and close_lnl(out["lnl"][0], O.log_likelihood(oo, pp))
+    md0, rows0 = pack_rows(do, [base])
+    assert close_lnl(do.loglike(md0, rows0)["lnl"][0], g["full_lnl"][0])
+    assert not np.isclose(out["lnl"][0], g["full_lnl"][0], rtol=1e-6)
+    # through the product API
+    m_code = synth.build_model(o)
+    m_paper = synth.build_model(o, emulator_cov="paper")
+    assert m_code.emulator_cov == "code"
+    P = synth.walker_ball(o, B=2, seed=3)
+    lp, lc = m_paper.log_likelihood_batch(P), m_code.log_likelihood_batch(P)
+    for b in range(2):
+        p = dict(synth.vector_to_oracle_params(P[b]))
+        assert close_lnl(lc[b], O.log_likelihood(oo, p))
+        assert close_lnl(lp[b], O.log_likelihood(oo, dict(p, emulator_cov="paper")))

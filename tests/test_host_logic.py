@@ -89,6 +89,18 @@ def test_setitem_getitem_delitem():
     np.testing.assert_allclose(m.grid_params, [6100.0, 4.2, -0.3])
 
 
+def test_emulator_covariance_form_switch_is_validated():
+    """``emulator_cov``: "code" (X^T Sigma_w^-1 X, spectrum_model.py:334-335: default, parity target) or "paper"
+    (Phi Sigma_w Phi^T, docs/api/emulator.rst:105); anything else is rejected at construction."""
+    from starfish_amd import synth
+
+    o = synth.make_order(N=128, m=4, seed=1)
+    assert synth.build_model(o).emulator_cov == "code"
+    assert synth.build_model(o, emulator_cov="paper").emulator_cov == "paper"
+    with pytest.raises(ValueError, match="emulator_cov"):
+        synth.build_model(o, emulator_cov="docs")
+
+
 def test_multi_order_data_is_rejected():
     o = synth.make_order(N=64, m=2)
     emu = Emulator(o["grid_points"], o["param_names"], o["emu_wl"], o["weights"], o["eigenspectra"],
