@@ -3535,7 +3535,8 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
 
     // ---- the task tables: one per queue size (ceil and floor of batch / 8)
     static const int cap = SF_TUNE_INT("SF_DF_CAP", SF_CHIP_WGS / SF_DF_QUEUES);  // workgroup slots of one XCD
-    static const int lead_bq = SF_TUNE_INT("SF_DF_LEAD_BQ", 0);  // lead slabs are split for queues of up to this many matrices
+    static const int lead_bq = SF_TUNE_INT("SF_DF_LEAD_BQ", 0);
+    static const int pt_tasks = SF_TUNE_INT("SF_DF_PT_TASKS", 16);  // partial-sum tasks of the chain per queue and panel (64 / 32 / 16 / 8: B = 32 14.9 / 14.8 / 14.55 / 14.45 ms, B = 48 20.8 / 20.2 / 20.2 / 20.6)  // lead slabs are split for queues of up to this many matrices
     const int kpb = GT / GK;
     const int st_cap = (int)std::min<size_t>(SF_SPLIT_MAX, std::max<size_t>(1, sf_split_region_tiles() / (2 * (size_t)batch)));
     a.pt_cap = st_cap;
@@ -3555,7 +3556,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
             st.off = off;
             // PT(., k+1, .): K slabs [fp / GK, k 8) of panel k+1 (everything left of panel k)
             const int cnt_pt = (k + 2 <= nt - 1) ? k * kpb - fp / GK : 0;
-            st.St = cnt_pt >= 8 ? sf_df_split(B, cnt_pt, st_cap, cap) : 0;
+            st.St = cnt_pt >= 8 ? sf_df_split(B, cnt_pt, st_cap, pt_tasks) : 0;
             thr_pt[(k + 1) & 1] += st.St;
             st.thr_pt = thr_pt[(k + 1) & 1];
             const int nk = (k * GT > fp ? k * GT - fp : 0) / GK;
