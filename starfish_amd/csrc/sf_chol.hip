@@ -3015,31 +3015,35 @@ int sf_launch_potrf_band(int n, int nband, int halfwidth, int batch, const doubl
 // (cfg 2 split over 2 / 4 / 8 GPUs: 64 / 32 / 16 matrices): the chain D(k) -> top(k) -> D(k+1) waits for workgroup slots
 // behind bulk workgroups that start and end together, the bulk launches wait for the chain's events, every launch fills
 // and drains the chip on its own (timelines in profiles/r04_*: the three streams 85-90 % busy, the matrix cores 0.49-0.74).
-// Here 512 workgroups (two per CU) stay resident and draw TASKS from one counter; a task waits for exactly the tasks whose
-// results it reads (monotone counters in global memory, agent scope) -- nothing else orders the work:
-//   C(b,k)    chain task of matrix b: the step of slab k for panel k-1 -- the split-K partial sums PT(b,k-1,.) added in split
-//             order, then the K tail over the last 128 columns, solve, L in place, tile (k,k) parked -- and the diagonal tile
-//             D(b,k) right behind it in the SAME workgroup (the tile never leaves the CU's caches; one task, no slot wait)
-//   PT(b,k,s) partial sums of slab k+1 for panel k over the columns LEFT of panel k-1: they depend on rest tasks two stages
-//             back, so they run long before C(b,k) needs the row they complete -- the chain's critical path per panel is
-//             reduce + 8 K slabs + solve + diagonal tile (~170 us), not a long-K loop
-//   R(b,i,k)  the fused panel step of slab i >= k+2 (MODE 0: its K loop starts as soon as row k is final, only the
-//             triangular solve waits for D(b,k)), or, while a stage has fewer tasks than the chip has workgroup slots,
-//             RP(b,i,k,s) partial sums + RR(b,i,k) reduce + epilogue
-// Tasks are drawn in an order in which every dependency precedes its dependants (stage k: PT(.,k+1,.), first half of
-// R(.,.,k), C(.,k+1), second half); a workgroup holds at most one task and only claimed tasks are waited for, so the
-// schedule cannot deadlock whatever the residency or placement of the workgroups.  The inverse tiles W_k of ALL panels are
-// kept (one per panel in the scratch the unfused sequence uses for its panel): no buffer of the chain is ever recycled.
-// Same arithmetic as the fused sequence (same kernels' bodies); the summation order differs where the split differs.
+// Here 512 workgroups (two per CU) stay resident and draw TASKS; a task waits for exactly the tasks whose results it reads
+// (monotone counters in global memory, agent scope) -- nothing else orders the work.  Per panel k and matrix b:
+//   C(b,k)      chain task: the step of slab k for panel k-1 -- the partial sums FP(b,k-1,1,.) added in split order, then the K
+//               tail over the last 128 columns, solve, L in place, tile (k,k) parked -- and the diagonal tile D(b,k) right
+//               behind it in the SAME workgroup.  The K work needs the FIRST half of the previous chain task (row k-1
+//               final), only the solve its second half (D(b,k-1)): it runs beside that diagonal tile, in another workgroup.
+//               Chain tasks are not queued: whichever workgroup finds one READY at the dispenser claims it (compare-and-swap
+//               on the matrix's chain counter) -- in a queue it waited until a workgroup had worked its way to it.
+//   FP(b,k,d,s) partial sums of the FRONT slabs k+d, d = 1..3, for panel k over the columns LEFT of panel k-1: they depend on
+//               tasks two stages back, so they run long before row k is final
+//   FR(b,k,d)   d = 2, 3: partial sums added + K tail + solve + L in place + own diagonal tile for slab k+d.  With the front
+//               three slabs wide the rows the chain needs next are one reduce-and-epilogue behind it (~150 us), not one
+//               long-K task: a lead slab as an ordinary task held the chain of 16 matrices at ~400 us per panel
+//   R(b,i,k)    the fused panel step of the slabs i >= k+4 (MODE 0: the K loop starts as soon as row k is final, only the
+//               triangular solve waits for D(b,k)), or, while a stage has fewer tasks than its XCD has workgroup slots,
+//               RP(b,i,k,s) partial sums + RR(b,i,k) reduce + epilogue
+// Queued tasks are drawn in an order in which every dependency precedes its dependants (stage k: FP(.,k+1,.,.), FR(.,k,.),
+// R / RP(.,.,k), RR(.,.,k)); a workgroup holds at most one task, only claimed tasks are waited for, a chain task is claimed
+// only when its K work can start: the schedule cannot deadlock whatever the residency or placement of the workgroups.  The
+// inverse tiles W_k of ALL panels are kept (one per panel, in the scratch the unfused sequence uses for its panel): no
+// buffer of the chain is ever recycled.  Same arithmetic as the fused sequence (the same kernels' bodies); the summation
+// order differs where the split differs.
 struct sf_df_stage {
     int off;      // first task of the stage's segment
-    int St;       // split of PT(., k+1, .): 0 = the chain task runs the whole K loop itself
-    int Sr;       // split of the rest tasks (1 = unsplit MODE 0)
-    int thr_pt;   // PT(b, k+1, .) arrivals C(b, k+2) waits for (cumulative over the stages of the same parity)
+    int St;       // split of FP(., k+1, ., .): 0 = the front tasks of panel k+1 run their whole K loops themselves
+    int Sr;       // split of the ordinary rest tasks (1 = unsplit MODE 0)
+    int thr_pt;   // FP(b, k+1, d, .) arrivals the front task of (b, k+1, d) waits for (cumulative over the panels of that parity)
     int thr_rp;   // RP(b, i, k, .) arrivals RR(b, i, k) waits for (cumulative)
     int dep;      // RP of this stage re-uses the partial-sum region of stage `dep` (same parity, split): wait for its reduces
-    int ndep;     // ... of which there are ndep
-    int Sl;       // while the rest tasks are unsplit: split of the two LEAD slabs k+2, k+3 (the rows the chain needs next), 0 = none
 };
 template <class S>
 __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy out of the constant address space)
@@ -3050,95 +3054,95 @@ __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy
     r.thr_pt = x.thr_pt;
     r.thr_rp = x.thr_rp;
     r.dep = x.dep;
-    r.ndep = x.ndep;
-    r.Sl = x.Sl;
     return r;
 }
 // One task queue per XCD: matrix b belongs to queue b % 8 (its slabs share the B operand L[panel rows, :k0] through that
 // XCD's L2 -- with ONE queue for the chip the operand was fetched by every XCD: L2 hit rate 0.14 instead of 0.38, 1.5 x the
-// HBM reads, 66 ms instead of 50 for 128 matrices); a workgroup serves the queue of the XCD it runs on and, once that is
-// exhausted, the others in turn.  Queues with the same number of matrices share a task table (at most two sizes).
+// HBM reads); a workgroup serves the queue of the XCD it runs on and, once that is exhausted, the others in turn.  Queues
+// with the same number of matrices share a task table (at most two sizes).
 #define SF_DF_QUEUES 8
-#define SF_DF_MAX_STAGES 48  // (two tables of 32-byte entries in the kernel arguments: < 4 KB)
+#define SF_DF_MAX_STAGES 64  // (two tables of 24-byte entries in the kernel arguments: < 4 KB)
+#define SF_DF_FRONT_MAX 6    // slabs k+1 .. k+front of panel k are front slabs (front <= 6, chosen by the batch size)
 #define SF_DF_QTILES (2 * SF_CHIP_WGS / SF_DF_QUEUES)  // partial-sum tiles per queue and stage parity
 struct sf_df_args {
     sf_panel_args p;  // matrix, right-hand side, generator, frame: the per-task fields are filled in by the kernel
-    int nt, batch;
+    int nt, batch, front;
     int bq[2], ntasks[2];  // table v serves the queues with bq[v] matrices
-    int pt_cap;       // largest split of the chain's partial sums: a matrix owns pt_cap tiles per panel parity in region 2
-    int *head, *abort_flag, *done_top, *done_D, *done_row, *pt_cnt, *rp_cnt, *lp_cnt, *stage_done;
-    int* chain_next;  // [batch]: the next chain task of every matrix (claimed by compare-and-swap once it is ready)
+    int pt_cap;       // largest split of the front partial sums: a (matrix, front slab) owns pt_cap tiles per panel parity in region 2
+    int *head, *abort_flag, *done_top, *done_D, *done_row, *fp_cnt, *rp_cnt, *stage_done;
+    int* chain_next;  // [batch][3]: the next chain task (d = 1) / front task (d = 2, 3) of every matrix (claimed by compare-and-swap once ready)
     double* T;        // per matrix: parked diagonal tile [GT x SF_LDT], then W_k for every panel
     int64_t sT;
-    double* part;     // three regions of sf_split_region_tiles() tiles: rest partial sums by stage parity, chain partial sums
+    double* part;     // three regions of sf_split_region_tiles() tiles: rest partial sums by stage parity, front partial sums
     int* info;
-    long long* dbg;   // tuning builds: per workgroup {ticks waiting, ticks in task bodies, ticks publishing, tasks} (100 MHz)
+    long long* dbg;   // tuning builds: per workgroup {ticks waiting, ticks in task bodies, tasks, ticks by type} (100 MHz)
     sf_df_stage st[2][SF_DF_MAX_STAGES];
 };
 #define SF_DF_LDS_DOUBLES ((37 * DBS + 128) > (4 * GT * GLD + 2 * GT) ? (37 * DBS + 128) : (4 * GT * GLD + 2 * GT))
-#define SF_DF_LDS_BYTES ((SF_DF_LDS_DOUBLES + 2) * sizeof(double))
+#define SF_DF_LDS_BYTES ((SF_DF_LDS_DOUBLES + 4) * sizeof(double))
 
 template <bool RHS>
 __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in) {
     extern __shared__ __attribute__((aligned(16))) double dsm[];
     double* sm = dsm;
     double(*red)[GT] = (double(*)[GT])(dsm + 4 * GT * GLD);
-    int* s_ints = (int*)(dsm + SF_DF_LDS_DOUBLES);  // [0] task id, [1] wait result: behind the kernels' LDS image, which starts at 0
+    int* s_ints = (int*)(dsm + SF_DF_LDS_DOUBLES);  // [0] task id, [1] wait result, [2] [3] chain task: behind the kernels' LDS image, which starts at 0
     const size_t region = sf_split_region_tiles_dev() * (size_t)(GT * GT);
     // The arguments are read through the kernel-argument segment pointer inside the task loop, and everything derived from
     // the thread index is recomputed per task (the index is laundered through an empty asm): otherwise hipcc hoists the
-    // lane-dependent invariants of all five inlined task bodies out of the loop and spills them (600 bytes of scratch per
+    // lane-dependent invariants of all the inlined task bodies out of the loop and spills them (600 bytes of scratch per
     // lane, scratch loads inside the MFMA loops).
     typedef const __attribute__((address_space(4))) sf_df_args sf_df_kargs;
     sf_df_kargs* ap = (sf_df_kargs*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)a_in;
     // (workgroup b of a launch runs on XCD b % 8 -- observed, not promised; placement is a speed matter only here: any
     // workgroup may serve any queue)
-    const unsigned xcc = blockIdx.x;
-    int qcur = (int)(xcc & (SF_DF_QUEUES - 1));
+    int qcur = (int)(blockIdx.x & (SF_DF_QUEUES - 1));
     int visited = 0;
     int kst = 0;  // stage hint: a workgroup draws the tasks of a queue in increasing order
     for (;;) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         sf_df_kargs& a = *ap;
-        const int nt = a.nt;
+        const int nt = a.nt, F = a.front;
         const int n = a.p.n, fp = a.p.fp;
         const int B = (a.batch - qcur + SF_DF_QUEUES - 1) / SF_DF_QUEUES;  // matrices of this queue: qcur, qcur + 8, ...
         const int v = B == a.bq[0] ? 0 : 1;
         const int ntasks = B > 0 ? a.ntasks[v] : 0;
-        // ---- dispenser.  Chain tasks first: they are not in the queues but claimed, per matrix and in order, by whichever
-        // workgroup finds one READY (its first-half dependencies met) -- in the queue a chain task waited until some workgroup
-        // had worked its way to it (150 us behind long rest tasks in the timeline of 16 matrices), and a task claimed before
-        // it is ready would only hold a workgroup spinning.  Then the queue of this workgroup's XCD, then the other queues.
+        // ---- dispenser.  Chain tasks first, then the queue of this workgroup's XCD, then the other queues.
         if (tid == 0) {
-            int t = -1, cb = 0, ck = 0;
+            int t = -1, cb = 0, ck = 0, cd = 1;
             if (sf_df_load(a.abort_flag) == 0) {
                 t = -2;
-                auto try_chain = [&](int qx) {  // a ready chain task among the matrices of queue qx?
+                auto try_chain = [&](int qx) {  // a ready chain / front task among the matrices of queue qx?
                     const int Bq = (a.batch - qx + SF_DF_QUEUES - 1) / SF_DF_QUEUES;
                     const int vq = Bq == a.bq[0] ? 0 : 1;
-                    for (int j = 0; j < Bq; ++j) {
-                        const int b1 = qx + SF_DF_QUEUES * j;
-                        const int k1 = sf_df_load(a.chain_next + b1);
-                        if (k1 >= nt) continue;
-                        bool ready = true;
-                        if (k1 >= 1) {
-                            const int kp = k1 - 1;
-                            ready = sf_df_load(a.done_top + b1) >= kp;
-                            if (ready && kp >= 1) {
-                                ready = sf_df_load(a.done_row + (size_t)b1 * nt + k1) >= kp;
-                                const int St = a.st[vq][kp - 1].St;
-                                if (ready && St > 0) ready = sf_df_load(a.pt_cnt + 2 * b1 + (kp & 1)) >= a.st[vq][kp - 1].thr_pt;
+                    for (int dd = 1; dd <= F; ++dd) {  // (the chain itself first)
+                        for (int j = 0; j < Bq; ++j) {
+                            const int b1 = qx + SF_DF_QUEUES * j;
+                            int* ctr = a.chain_next + SF_DF_FRONT_MAX * b1 + dd - 1;
+                            const int k1 = sf_df_load(ctr);  // d = 1: chain task index (panel k1 - 1); d >= 2: panel
+                            const int kp = dd == 1 ? k1 - 1 : k1;
+                            if (dd == 1 ? k1 >= nt : kp + dd > nt - 1) continue;
+                            bool ready = true;
+                            if (kp >= 0) {
+                                ready = sf_df_load(a.done_top + b1) >= kp;
+                                if (ready && kp >= 1) {
+                                    ready = sf_df_load(a.done_row + (size_t)b1 * nt + kp + dd) >= kp;
+                                    const int St = a.st[vq][kp - 1].St;
+                                    if (ready && St > 0)
+                                        ready = sf_df_load(a.fp_cnt + 2 * SF_DF_FRONT_MAX * b1 + SF_DF_FRONT_MAX * (kp & 1) + dd - 1) >= a.st[vq][kp - 1].thr_pt;
+                                }
                             }
-                        }
-                        if (!ready) continue;
-                        int expect = k1;
-                        if (__hip_atomic_compare_exchange_strong(a.chain_next + b1, &expect, k1 + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                 __HIP_MEMORY_SCOPE_AGENT)) {
-                            cb = b1;
-                            ck = k1;
-                            return true;
+                            if (!ready) continue;
+                            int expect = k1;
+                            if (__hip_atomic_compare_exchange_strong(ctr, &expect, k1 + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                                cb = b1;
+                                ck = k1;
+                                cd = dd;
+                                return true;
+                            }
                         }
                     }
                     return false;
@@ -3154,7 +3158,11 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     for (int qx = 0; qx < SF_DF_QUEUES && t == -2; ++qx)
                         if (try_chain(qx)) t = -3;
                     if (t == -2) {
-                        for (int b1 = 0; b1 < a.batch; ++b1) live = live || sf_df_load(a.chain_next + b1) < nt;
+                        for (int b1 = 0; b1 < a.batch; ++b1) {
+                            live = live || sf_df_load(a.chain_next + SF_DF_FRONT_MAX * b1) < nt;
+                            for (int dd = 2; dd <= F; ++dd)
+                                live = live || sf_df_load(a.chain_next + SF_DF_FRONT_MAX * b1 + dd - 1) + dd <= nt - 1;
+                        }
                         if (!live) t = -5;
                         else __builtin_amdgcn_s_sleep(64);
                     }
@@ -3163,10 +3171,12 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
             s_ints[0] = t;
             s_ints[2] = cb;
             s_ints[3] = ck;
+            s_ints[4] = cd;
         }
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(s_ints[0]);  // (wave-uniform: everything decoded from it lives in SGPRs)
         const int chain_b = __builtin_amdgcn_readfirstlane(s_ints[2]), chain_k = __builtin_amdgcn_readfirstlane(s_ints[3]);
+        const int chain_d = __builtin_amdgcn_readfirstlane(s_ints[4]);
         __syncthreads();
         if (t == -1) {  // a wait timed out somewhere: nothing of this launch can be trusted
             if (a.info)
@@ -3182,96 +3192,57 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
             continue;
         }
 
-        // ---- decode
-        enum { T_C, T_PT, T_R, T_RP, T_RR };
-        int type, bl, k, i = 0, sp = 0, S = 1, lead = 0;
-        // rest tile -> (slab, matrix): the two slabs the chain needs next come first, for every matrix; the others matrix by
-        // matrix, so that the tasks running side by side on an XCD stream the SAME B operand L[panel rows, :k0] more or
-        // less in step (slab-major order: 16 matrices x 2 MB of B operand in flight per XCD -- nothing of it survives in the L2)
-        auto rest_tile = [&](int tile, int kk, int nrest) {
-            const int lead = min(nrest, 2);
-            if (tile < lead * B) {
-                i = kk + 2 + tile / B;
-                bl = tile % B;
-            } else {
-                const int u2 = tile - lead * B, per = nrest - lead;
-                bl = u2 / per;
-                i = kk + 2 + lead + (u2 - bl * per);
-            }
-        };
+        // ---- decode: k = panel, i = slab, d = i - k for front tasks
+        enum { T_C, T_FP, T_FR, T_R, T_RP, T_RR };
+        int type, bl = 0, k, i = 0, sp = 0, S = 1, d = 0;
         int bchain = -1;
         if (t == -3) {
-            type = T_C;
+            type = chain_d == 1 ? T_C : T_FR;
             bchain = chain_b;
-            bl = 0;
             k = chain_k;
+            d = chain_d;
+            i = k + d;
         } else {
             while (kst + 1 < nt - 1 && t >= a.st[v][kst + 1].off) ++kst;
             const sf_df_stage st = sf_df_stage_of(a.st[v][kst]);
-            const int nrest = nt - kst - 2;
-            const int n_pt = B * st.St;
-            // lead slabs (only while the rest tasks are unsplit): their partial sums and reduces come first
-            const int nl = st.Sl > 0 ? min(nrest, 2) : 0;
-            const int n_lp = B * nl * st.Sl, n_lr = B * nl;
-            const int n_r = B * (nrest - nl);
-            const int n_r1 = st.Sr > 1 ? n_r * st.Sr : (n_r + 1) / 2;
-            auto plain_tile = [&](int tile) {  // the slabs behind the lead slabs, matrix by matrix
-                const int per = nrest - nl;
-                bl = tile / per;
-                i = kst + 2 + nl + (tile - bl * per);
-            };
+            // front slabs of panel kst + 1 that exist, front slabs d >= 2 of this panel, ordinary slabs of this panel
+            const int nF = max(0, min(F, nt - 1 - (kst + 1)));
+            const int nord = max(0, nt - kst - 1 - F);
+            const int n_fp = B * nF * st.St;
+            const int n_r1 = B * nord * (st.Sr > 1 ? st.Sr : 1);
             int u = t - st.off;
-            if (u < n_pt) {
-                type = T_PT;
-                k = kst + 1;  // partial sums of slab k+1 for panel k
+            if (u < n_fp) {
+                type = T_FP;
+                k = kst + 1;
                 S = st.St;
+                d = 1 + u / (B * S);  // (d = 1 first: the chain's own partial sums)
+                u -= (d - 1) * B * S;
                 bl = u / S;
                 sp = u - bl * S;
-            } else if ((u -= n_pt) < n_lp) {
-                type = T_RP;
-                lead = 1;
+                i = k + d;
+            } else if ((u -= n_fp) < n_r1) {
                 k = kst;
-                S = st.Sl;
-                const int tile = u / S;
+                S = st.Sr;
+                type = S > 1 ? T_RP : T_R;
+                const int tile = u / S;  // ordinary slabs matrix by matrix: tasks side by side on an XCD stream the same B operand
                 sp = u - tile * S;
-                i = k + 2 + tile / B;
-                bl = tile % B;
-            } else if ((u -= n_lp) < n_lr) {
-                type = T_RR;
-                lead = 1;
-                k = kst;
-                S = st.Sl;
-                i = k + 2 + u / B;
-                bl = u % B;
-            } else if ((u -= n_lr) < n_r1) {
-                k = kst;
-                if (st.Sr > 1) {
-                    type = T_RP;
-                    S = st.Sr;
-                    const int tile = u / S;
-                    sp = u - tile * S;
-                    rest_tile(tile, k, nrest);
-                } else {
-                    type = T_R;
-                    if (nl) plain_tile(u);
-                    else rest_tile(u, k, nrest);
-                }
+                bl = tile / nord;
+                i = k + 1 + F + (tile - bl * nord);
             } else {
                 u -= n_r1;
                 k = kst;
-                type = st.Sr > 1 ? T_RR : T_R;
                 S = st.Sr;
-                if (st.Sr > 1) rest_tile(u, k, nrest);
-                else if (nl) plain_tile(n_r1 + u);
-                else rest_tile(n_r1 + u, k, nrest);
+                type = T_RR;
+                bl = u / nord;
+                i = k + 1 + F + (u - bl * nord);
             }
         }
-        lead = __builtin_amdgcn_readfirstlane(lead);
         bl = __builtin_amdgcn_readfirstlane(bl);  // (the divisions above ran on the VALU)
         i = __builtin_amdgcn_readfirstlane(i);
         sp = __builtin_amdgcn_readfirstlane(sp);
         k = __builtin_amdgcn_readfirstlane(k);
         S = __builtin_amdgcn_readfirstlane(S);
+        d = __builtin_amdgcn_readfirstlane(d);
         type = __builtin_amdgcn_readfirstlane(type);
         const int b = bchain >= 0 ? bchain : qcur + SF_DF_QUEUES * bl;  // the matrix
         const int vb = bchain >= 0 ? (((a.batch - (b & (SF_DF_QUEUES - 1)) + SF_DF_QUEUES - 1) / SF_DF_QUEUES) == a.bq[0] ? 0 : 1) : v;  // its queue's table
@@ -3292,33 +3263,41 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
         q.lds_int = s_ints + 1;
         q.sW = a.sT;
         auto Wof = [&](int kk) { return a.T + (size_t)(1 + kk) * GT * SF_LDT; };
+        // front partial sums of (panel parity, front slab d, matrix): pt_cap tiles each in region 2; the body indexes them with
+        // the matrix number b and the split S of the panel: base = slot of (parity, d, b) minus b S
+        auto fpart = [&](int kk, int dd, int SS) {
+            return a.part + 2 * region + (((int64_t)((kk & 1) * F + dd - 1) * a.batch + b) * a.pt_cap - (int64_t)b * SS) * (GT * GT);
+        };
+        int* fcnt = a.fp_cnt + 2 * SF_DF_FRONT_MAX * b;
         bool ok = true;
-        if (type == T_C) {
-            // the chain's waves share their SIMDs with rest tasks issuing MFMAs back to back
-            __builtin_amdgcn_s_setprio(2);
-            q.Sout = a.T;  // (g.sS = a.sT, g.ldS = SF_LDT)
-            if (k == 0) {
+        if (type == T_C || type == T_FR) {
+            // the step of the front slab k+d (chain: of slab k for panel kp = k - 1) for panel kp: partial sums, K tail, epilogue
+            const int kp = type == T_C ? k - 1 : k;
+            const int slab = kp + d;
+            if (type == T_C) {
+                __builtin_amdgcn_s_setprio(2);  // the chain's waves share their SIMDs with rest tasks issuing MFMAs back to back
+                q.Sout = a.T;                   // (g.sS = a.sT, g.ldS = SF_LDT)
+            }
+            if (kp < 0) {
                 // start of the factorisation: diagonal tile 0 goes to the scratch unchanged (pw = 0)
                 if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 __syncthreads();
                 sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
             } else {
-                const int kp = k - 1;  // the step of slab k for panel kp
-                const sf_df_stage stp = sf_df_stage_of(a.st[vb][kp > 0 ? kp - 1 : 0]);  // (PT(., kp, .) belongs to stage kp - 1)
+                const sf_df_stage stp = sf_df_stage_of(a.st[vb][kp > 0 ? kp - 1 : 0]);  // (FP(., kp, ., .) belongs to stage kp - 1)
                 const int St = kp >= 1 ? stp.St : 0;
                 q.k0 = kp * GT;
                 q.pw = min(GT, n - q.k0);
-                q.row0 = k * GT;
+                q.row0 = slab * GT;
                 q.Wt = Wof(kp);
                 q.ksplit = St;
                 q.ktail = St > 0 ? (kp - 1) * (GT / GK) : 0;
-                q.part = a.part + 2 * region + ((size_t)(kp & 1) * a.batch * a.pt_cap + (size_t)b * (a.pt_cap - St)) * (GT * GT);
-                // row k left of the tail (rest task of stage kp - 1), the previous chain task (row kp, W_kp), the partial sums
-                // (partial sums + K tail need row kp final = the FIRST half of the previous chain task; only the solve needs its
-                // second half, the diagonal tile D(kp): this task's K work runs beside D(kp), in another workgroup)
+                q.part = fpart(kp, d, St);
+                // the slab's own row left of the tail; row kp final = the FIRST half of the chain task C(b,kp) (only the solve
+                // needs its second half, the diagonal tile: this task's K work runs beside it); the partial sums
                 bool dready = false;
-                ok = sf_df_wait(kp >= 1 ? a.done_row + (size_t)b * nt + k : nullptr, kp, a.done_top + b, kp,
-                                St > 0 ? a.pt_cnt + 2 * b + (kp & 1) : nullptr, stp.thr_pt, a.done_D + b, kp + 1, &dready, a.abort_flag,
+                ok = sf_df_wait(kp >= 1 ? a.done_row + (size_t)b * nt + slab : nullptr, kp, a.done_top + b, kp,
+                                St > 0 ? fcnt + SF_DF_FRONT_MAX * (kp & 1) + d - 1 : nullptr, stp.thr_pt, a.done_D + b, kp + 1, &dready, a.abort_flag,
                                 tid, s_ints + 1);
                 if (!dready) {
                     q.wflag = a.done_D + b;
@@ -3327,7 +3306,14 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 SF_DF_MARK();
                 if (ok) sf_panel_body<RHS, 3>(g, q, b, sm, red, tid);
             }
-            if (ok) {
+            if (ok && type == T_FR) {
+                __syncthreads();
+                if (tid == 0) {
+                    sf_df_release();
+                    sf_df_set(a.done_row + (size_t)b * nt + slab, kp + 1);
+                }
+            }
+            if (ok && type == T_C) {
                 __syncthreads();
 #ifdef SF_TUNING
                 dbg_top = wall_clock64();
@@ -3348,40 +3334,42 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     sf_df_set(a.done_D + b, k + 1);
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (type == T_C) __builtin_amdgcn_s_setprio(0);
         } else {
             const int k0 = k * GT;
             const int nk = (k0 > fp ? k0 - fp : 0) / GK;
             q.k0 = k0;
             q.pw = min(GT, n - k0);
             q.Wt = Wof(k);
-            if (type == T_PT) {
-                // slab k+1, panel k, K slabs [fp / GK, (k - 1) 8): rows k and k+1 through panel k-2; the region's previous user
+            q.row0 = i * GT;
+            if (type == T_FP) {
+                // slab k+d, panel k, K slabs [fp / GK, (k - 1) 8): rows k and k+d through panel k-2; the slots' previous user (the
+                // front task of (b, k-2, d)) must have read them: the chain's second half for d = 1, the row counter otherwise
                 const int cnt = (k - 1) * (GT / GK) - fp / GK;
-                q.row0 = (k + 1) * GT;
                 q.ksplit = S;
                 q.kchunk = (cnt + S - 1) / S;
                 q.kstop = (k - 1) * (GT / GK);
-                q.part = a.part + 2 * region + ((size_t)(k & 1) * a.batch * a.pt_cap + (size_t)b * (a.pt_cap - S)) * (GT * GT);
-                ok = sf_df_wait(a.done_row + (size_t)b * nt + k, k - 1, a.done_row + (size_t)b * nt + k + 1, k - 1, a.done_D + b, k,
-                                nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
+                q.part = fpart(k, d, S);
+                ok = sf_df_wait(a.done_row + (size_t)b * nt + k, k - 1, a.done_row + (size_t)b * nt + i, k - 1,
+                                d == 1 ? a.done_D + b : a.done_row + (size_t)b * nt + i - 2, d == 1 ? k : k - 1, nullptr, 0, nullptr,
+                                a.abort_flag, tid, s_ints + 1);
                 SF_DF_MARK();
                 if (ok) {
                     sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
                     __syncthreads();
                     if (tid == 0) {
                         sf_df_release();
-                        sf_df_add(a.pt_cnt + 2 * b + (k & 1), 1);
+                        sf_df_add(fcnt + SF_DF_FRONT_MAX * (k & 1) + d - 1, 1);
                     }
                 }
             } else {
                 const sf_df_stage st = sf_df_stage_of(a.st[v][k]);
-                q.row0 = i * GT;
+                const int nord = nt - k - 1 - F;
                 q.ksplit = S;
                 q.kchunk = (nk + S - 1) / S;
-                // (the body indexes the partial sums with the matrix number b: slot of (slab, local matrix) minus b S)
+                // (the body indexes the partial sums with the matrix number b: slot of (local matrix, slab) minus b S)
                 q.part = a.part + (size_t)(k & 1) * region +
-                         ((int64_t)qcur * SF_DF_QTILES + ((int64_t)(i - k - 2) * B + bl - b) * S) * (GT * GT);
+                         ((int64_t)qcur * SF_DF_QTILES + ((int64_t)bl * nord + (i - k - 1 - F) - b) * S) * (GT * GT);
                 int* rowflag = a.done_row + (size_t)b * nt + i;
                 int* sdone = a.stage_done + (size_t)qcur * nt;
                 if (type == T_R) {
@@ -3398,15 +3386,12 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     if (ok) sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
                 } else if (type == T_RP) {
                     ok = sf_df_wait(k >= 1 ? a.done_top + b : nullptr, k, rowflag, k, st.dep >= 0 ? sdone + st.dep : nullptr,
-                                    st.ndep, nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
+                                    B * (nt - st.dep - 1 - F), nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
                     SF_DF_MARK();
                     if (ok) sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
                 } else {
-                    // (a lead slab's partial-sum counter is cumulative over the two stages in which the slab leads)
-                    int thr = st.thr_rp;
-                    if (lead) thr = st.Sl + ((i == k + 2 && k >= 1) ? a.st[v][k - 1].Sl : 0);
-                    ok = sf_df_wait((lead ? a.lp_cnt : a.rp_cnt) + (size_t)b * nt + i, thr, a.done_D + b, k + 1, nullptr, 0, nullptr, 0,
-                                    nullptr, a.abort_flag, tid, s_ints + 1);
+                    ok = sf_df_wait(a.rp_cnt + (size_t)b * nt + i, st.thr_rp, a.done_D + b, k + 1, nullptr, 0, nullptr, 0, nullptr,
+                                    a.abort_flag, tid, s_ints + 1);
                     SF_DF_MARK();
                     if (ok) sf_panel_body<RHS, 2>(g, q, b, sm, red, tid);
                 }
@@ -3415,7 +3400,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 if (ok && tid == 0) {
                     sf_df_release();
                     if (type == T_RP) {
-                        sf_df_add((lead ? a.lp_cnt : a.rp_cnt) + (size_t)b * nt + i, 1);
+                        sf_df_add(a.rp_cnt + (size_t)b * nt + i, 1);
                     } else {
                         sf_df_set(rowflag, k + 1);
                         if (type == T_RR) sf_df_add(sdone + k, 1);
@@ -3428,14 +3413,14 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
 #ifdef SF_TUNING
         if (a.dbg && tid == 0) {
             const long long t2 = wall_clock64();
-            long long* d = a.dbg + 8 * (size_t)blockIdx.x;
-            d[0] += dbg_t1 - dbg_t0;
-            d[1] += t2 - dbg_t1;
-            d[2] += 1;
-            d[7] = 1 + (long long)(xcc & 0xffff) + ((long long)qcur << 16) + ((long long)visited << 24);
-            if (b == 0 && k < 64) {  // timeline of matrix 0: chain task, its partial sums, the lead slab's tasks
+            long long* dd = a.dbg + 10 * (size_t)blockIdx.x;
+            dd[0] += dbg_t1 - dbg_t0;
+            dd[1] += t2 - dbg_t1;
+            dd[2] += 1;
+            dd[3 + type] += t2 - dbg_t0;
+            if (b == 0 && k < 64) {  // timeline of matrix 0: chain task, its partial sums, the front slab d = 2
                 long long* tr = a.dbg + 10 * SF_CHIP_WGS + 16 * k;
-                const int slot = type == T_C ? 0 : (type == T_PT && sp == 0) ? 3 : (i == k + 2 && sp == 0 && type != T_RR) ? 6 : (i == k + 2 && type == T_RR) ? 9 : -1;
+                const int slot = type == T_C ? 0 : (type == T_FP && d == 1 && sp == 0) ? 3 : (type == T_FP && d == 2 && sp == 0) ? 6 : (type == T_FR && d == 2) ? 9 : -1;
                 if (slot >= 0) {
                     tr[slot] = dbg_t0;
                     tr[slot + 1] = dbg_t1;
@@ -3443,11 +3428,6 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     if (type == T_C) tr[12] = dbg_top;
                 }
             }
-            if (type == T_R) {  // per-stage totals of the unsplit rest tasks (body only, waits excluded)
-                atomicAdd((unsigned long long*)(a.dbg + 8 * SF_CHIP_WGS + 2 * k), (unsigned long long)(t2 - dbg_t1));
-                atomicAdd((unsigned long long*)(a.dbg + 8 * SF_CHIP_WGS + 2 * k + 1), 1ull);
-            }
-            d[3 + (type == T_C ? 0 : type == T_PT ? 1 : type == T_R ? 2 : type == T_RP ? 3 : 4)] += t2 - dbg_t0;
         }
 #endif
     }
@@ -3482,7 +3462,8 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     const int nt = (n + GT - 1) / GT;
     // counters: in the two inverse-tile buffers of the launch sequences (2 x batch x sW doubles), which this sequence does not use
     int* flags = (int*)Wt2;
-    const size_t nflags = 64 + (size_t)batch * (3 * nt + 5) + (size_t)SF_DF_QUEUES * nt + 2 * 10 * SF_CHIP_WGS + 8 + 2 * 16 * 64;
+    const size_t ndbg = 2 * (10 * SF_CHIP_WGS + 16 * 64);
+    const size_t nflags = 64 + (size_t)batch * (2 * nt + 2 + 3 * SF_DF_FRONT_MAX) + (size_t)SF_DF_QUEUES * nt + 8 + ndbg;
     if (nt - 1 > SF_DF_MAX_STAGES || nflags * sizeof(int) > 2 * (size_t)batch * sW * sizeof(double)) {
         sf_set_error("potrf: dataflow sequence: %d panels / %d matrices do not fit its tables", nt, batch);
         return SF_EINVAL;
@@ -3492,12 +3473,11 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.abort_flag = flags + 32;
     a.done_top = flags + 64;
     a.done_D = a.done_top + batch;
-    a.pt_cnt = a.done_D + batch;            // [batch][2]
-    a.done_row = a.pt_cnt + 2 * batch;      // [batch][nt]
+    a.chain_next = a.done_D + batch;
+    a.fp_cnt = a.chain_next + SF_DF_FRONT_MAX * batch;  // [batch][2][SF_DF_FRONT_MAX]
+    a.done_row = a.fp_cnt + 2 * SF_DF_FRONT_MAX * batch;      // [batch][nt]
     a.rp_cnt = a.done_row + (size_t)batch * nt;
-    a.lp_cnt = a.rp_cnt + (size_t)batch * nt;
-    a.stage_done = a.lp_cnt + (size_t)batch * nt;  // [SF_DF_QUEUES][nt]
-    a.chain_next = a.stage_done + (size_t)SF_DF_QUEUES * nt;
+    a.stage_done = a.rp_cnt + (size_t)batch * nt;  // [SF_DF_QUEUES][nt]
     SF_HIP(hipMemsetAsync(flags, 0, nflags * sizeof(int), s));
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
 
@@ -3523,6 +3503,13 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
         g.tilemap = gen->tilemap;
         g.nt128 = gen->nt128;
     }
+    // front width: the rows the chain needs next must be a reduce-and-epilogue behind it, and the first ORDINARY slab of a
+    // stage (a long-K task, or partial sums + reduce) gets `front` chain periods before the front needs its row.  Front tasks
+    // cost more than ordinary ones (partial sums written and read back).  N = 4096, front 1 / 2 / 3 / 4 / 5 / 6: B = 16 8.95 /
+    // 8.85 / 8.85 / 8.95 / 8.5 / 8.45 ms, B = 32 14.7 / 14.65 / 14.8 / 14.85 / 14.85 / 15.05, B = 48 20.3 / 20.5 / 20.8 / 21.3 / 21.5 / 22.2
+    static const int front_env = SF_TUNE_INT("SF_DF_FRONT", 0);
+    const int F = std::max(1, std::min(SF_DF_FRONT_MAX, front_env > 0 ? front_env : (batch <= 20 ? 6 : 2)));
+    a.front = F;
     a.nt = nt;
     a.batch = batch;
     a.T = T;
@@ -3530,15 +3517,16 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.part = part;
     a.info = info;
 #ifdef SF_TUNING
-    if (SF_TUNE_FLAG("SF_DF_VERBOSE")) a.dbg = (long long*)(flags + ((nflags - 2 * 10 * SF_CHIP_WGS - 8 - 2 * 16 * 64 + 1) & ~(size_t)1));
+    if (SF_TUNE_FLAG("SF_DF_VERBOSE")) a.dbg = (long long*)(flags + ((nflags - ndbg + 1) & ~(size_t)1));
 #endif
 
     // ---- the task tables: one per queue size (ceil and floor of batch / 8)
     static const int cap = SF_TUNE_INT("SF_DF_CAP", SF_CHIP_WGS / SF_DF_QUEUES);  // workgroup slots of one XCD
-    static const int lead_bq = SF_TUNE_INT("SF_DF_LEAD_BQ", 0);
-    static const int pt_tasks = SF_TUNE_INT("SF_DF_PT_TASKS", 16);  // partial-sum tasks of the chain per queue and panel (64 / 32 / 16 / 8: B = 32 14.9 / 14.8 / 14.55 / 14.45 ms, B = 48 20.8 / 20.2 / 20.2 / 20.6)  // lead slabs are split for queues of up to this many matrices
+    // front partial-sum tasks per queue, panel and front slab (64 / 32 / 16 / 8 with a one-slab front: B = 32 14.9 / 14.8 / 14.55 /
+    // 14.45 ms, B = 48 20.8 / 20.2 / 20.2 / 20.6)
+    static const int pt_tasks = SF_TUNE_INT("SF_DF_PT_TASKS", 16);
     const int kpb = GT / GK;
-    const int st_cap = (int)std::min<size_t>(SF_SPLIT_MAX, std::max<size_t>(1, sf_split_region_tiles() / (2 * (size_t)batch)));
+    const int st_cap = (int)std::min<size_t>(SF_SPLIT_MAX, std::max<size_t>(1, sf_split_region_tiles() / (2 * (size_t)F * (size_t)batch)));
     a.pt_cap = st_cap;
     a.bq[0] = (batch + SF_DF_QUEUES - 1) / SF_DF_QUEUES;
     a.bq[1] = batch / SF_DF_QUEUES;
@@ -3549,41 +3537,27 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
             continue;
         }
         int off = 0, thr_pt[2] = {0, 0}, thr_rp = 0, last_split[2] = {-1, -1};
-        int nred_of[SF_DF_MAX_STAGES + 1] = {0};
         for (int k = 0; k + 1 < nt; ++k) {
             sf_df_stage& st = a.st[v][k];
-            const int nrest = nt - k - 2;
             st.off = off;
-            // PT(., k+1, .): K slabs [fp / GK, k 8) of panel k+1 (everything left of panel k)
-            const int cnt_pt = (k + 2 <= nt - 1) ? k * kpb - fp / GK : 0;
+            // FP(., k+1, ., .): K slabs [fp / GK, k 8) of panel k+1 (everything left of panel k)
+            const int nF = std::max(0, std::min(F, nt - 1 - (k + 1)));
+            const int nord = std::max(0, nt - k - 1 - F);
+            const int cnt_pt = nF > 0 ? k * kpb - fp / GK : 0;
             st.St = cnt_pt >= 8 ? sf_df_split(B, cnt_pt, st_cap, pt_tasks) : 0;
             thr_pt[(k + 1) & 1] += st.St;
             st.thr_pt = thr_pt[(k + 1) & 1];
             const int nk = (k * GT > fp ? k * GT - fp : 0) / GK;
-            st.Sr = nrest > 0 ? sf_df_split((long long)B * nrest, nk, SF_SPLIT_MAX, cap) : 1;
-            while (st.Sr > 1 && (size_t)B * nrest * st.Sr > SF_DF_QTILES) st.Sr /= 2;
-            // lead slabs: while the chain is what the rest waits for (few matrices per queue), the two slabs it needs next
-            // are split even when the stage as a whole is not
-            st.Sl = 0;
-            const int nl = std::min(nrest, 2);
-            if (st.Sr == 1 && nl > 0 && B <= lead_bq) {
-                st.Sl = sf_df_split((long long)B * nl, nk, SF_SPLIT_MAX, cap);
-                while (st.Sl > 1 && (size_t)B * nl * st.Sl > SF_DF_QTILES) st.Sl /= 2;
-                if (st.Sl < 2) st.Sl = 0;
-            }
+            st.Sr = nord > 0 ? sf_df_split((long long)B * nord, nk, SF_SPLIT_MAX, cap) : 1;
+            while (st.Sr > 1 && (size_t)B * nord * st.Sr > SF_DF_QTILES) st.Sr /= 2;
             st.dep = -1;
-            st.ndep = 0;
-            const int nred = st.Sr > 1 ? B * nrest : (st.Sl > 0 ? B * nl : 0);  // reduce tasks of this stage
-            if (st.Sr > 1) thr_rp += st.Sr;
-            if (nred > 0) {
+            if (st.Sr > 1) {
+                thr_rp += st.Sr;
                 st.dep = last_split[k & 1];
-                st.ndep = st.dep >= 0 ? nred_of[st.dep] : 0;
                 last_split[k & 1] = k;
             }
-            nred_of[k] = nred;
             st.thr_rp = thr_rp;
-            off += B * st.St + (st.Sl > 0 ? B * nl * (st.Sl + 1) : 0) +
-                   B * (nrest - (st.Sl > 0 ? nl : 0)) * (st.Sr > 1 ? st.Sr + 1 : 1);
+            off += B * nF * st.St + B * nord * (st.Sr > 1 ? st.Sr + 1 : 1);
         }
         a.ntasks[v] = off;
     }
@@ -3596,21 +3570,18 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
         const double rows = (double)(n - (k + 1) * GT);
         flops += (2.0 * (k0 > fp ? k0 - fp : 0) * rows * pw + rows * pw * (double)pw + (double)GT * rows * pw) * batch;
     }
-    long long total = 0;
+    long long total = (long long)batch * nt * F;  // the chain and front tasks
     for (int qx = 0; qx < SF_DF_QUEUES; ++qx) {
         const int B = (batch - qx + SF_DF_QUEUES - 1) / SF_DF_QUEUES;
         if (B > 0) total += a.ntasks[B == a.bq[0] ? 0 : 1];
     }
     static const int grid_env = SF_TUNE_INT("SF_DF_GRID", SF_CHIP_WGS);
-    total += (long long)batch * nt;  // (+ the chain tasks)
     const int grid = (int)std::min<long long>(total, grid_env);
 #ifdef SF_TUNING
     if (SF_TUNE_FLAG("SF_DF_VERBOSE")) {
-        int occ = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_potrf_dataflow<false>, 512, SF_DF_LDS_BYTES);
-        fprintf(stderr, "dataflow: n=%d nt=%d batch=%d tasks=%lld grid=%d occupancy=%d/CU lds=%zu bq=%d/%d St/Sr:", n, nt, batch, total, grid,
-                occ, (size_t)SF_DF_LDS_BYTES, a.bq[0], a.bq[1]);
-        for (int k = 0; k + 1 < nt; ++k) fprintf(stderr, " %d/%d/%d", a.st[0][k].St, a.st[0][k].Sr, a.st[0][k].Sl);
+        fprintf(stderr, "dataflow: n=%d nt=%d batch=%d tasks=%lld grid=%d lds=%zu bq=%d/%d St/Sr:", n, nt, batch, total, grid,
+                (size_t)SF_DF_LDS_BYTES, a.bq[0], a.bq[1]);
+        for (int k = 0; k + 1 < nt; ++k) fprintf(stderr, " %d/%d", a.st[0][k].St, a.st[0][k].Sr);
         fprintf(stderr, "\n");
     }
 #endif
@@ -3627,41 +3598,29 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
         static long long host[10 * SF_CHIP_WGS + 16 * 64];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(host, a.dbg, sizeof(host), hipMemcpyDeviceToHost);
-        double w = 0, bd = 0, nn = 0, ty[5] = {0, 0, 0, 0, 0};
+        double w = 0, bd = 0, nn = 0, ty[6] = {0, 0, 0, 0, 0, 0};
         long long wmax = 0, bmax = 0;
         for (int i = 0; i < grid; ++i) {
-            w += host[8 * i];
-            bd += host[8 * i + 1];
-            nn += host[8 * i + 2];
-            for (int j = 0; j < 5; ++j) ty[j] += host[8 * i + 3 + j];
-            wmax = std::max(wmax, host[8 * i]);
-            bmax = std::max(bmax, host[8 * i] + host[8 * i + 1]);
+            w += host[10 * i];
+            bd += host[10 * i + 1];
+            nn += host[10 * i + 2];
+            for (int j = 0; j < 6; ++j) ty[j] += host[10 * i + 3 + j];
+            wmax = std::max(wmax, host[10 * i]);
+            bmax = std::max(bmax, host[10 * i] + host[10 * i + 1]);
         }
-        int hist[16] = {0};
-        for (int i = 0; i < grid; ++i) hist[(host[8 * i + 7] - 1) & 15]++;
-        fprintf(stderr, "dataflow xcc histogram:");
-        for (int i = 0; i < 16; ++i) fprintf(stderr, " %d", hist[i]);
-        fprintf(stderr, " | raw of wg 0..3: %llx %llx %llx %llx\n", host[7], host[15], host[23], host[31]);
-        fprintf(stderr, "dataflow R tasks, us per task / us per K slab by stage:");
-        for (int k = 0; k + 2 < nt; ++k) {
-            const long long* e = host + 8 * SF_CHIP_WGS + 2 * k;
-            if (e[1]) fprintf(stderr, " %d:%.0f/%.2f", k, e[0] / 100.0 / e[1], k ? e[0] / 100.0 / e[1] / (8.0 * k) : 0.0);
-        }
-        fprintf(stderr, "\n");
         if (SF_TUNE_FLAG("SF_DF_TRACE")) {
             const long long* tr = host + 10 * SF_CHIP_WGS;
             long long t0 = tr[0];
-            fprintf(stderr, "matrix 0, us since its first task: k | C claim start end | PT(k) claim start end | lead R(k+2,k) claim start end | lead RR claim start end\n");
+            fprintf(stderr, "matrix 0, us since its first task: k | C claim start end | FP(k,1) claim start end | FP(k,2) claim start end | FR(k,2) claim start end\n");
             for (int k = 0; k < nt && k < 64; ++k) {
                 fprintf(stderr, "%2d |", k);
                 for (int j = 0; j < 12; ++j) fprintf(stderr, "%s%8.1f", j % 3 == 0 && j ? " |" : "", tr[16 * k + j] ? (tr[16 * k + j] - t0) / 100.0 : 0.0);
-                fprintf(stderr, " | C: panel part %6.1f, D %6.1f", (tr[16 * k + 12] - tr[16 * k + 1]) / 100.0, (tr[16 * k + 2] - tr[16 * k + 12]) / 100.0);
-                fprintf(stderr, "\n");
+                fprintf(stderr, " | C: panel part %6.1f, D %6.1f\n", (tr[16 * k + 12] - tr[16 * k + 1]) / 100.0, (tr[16 * k + 2] - tr[16 * k + 12]) / 100.0);
             }
         }
-        fprintf(stderr, "dataflow per workgroup: waiting %.2f ms (max %.2f), bodies %.2f ms, busy max %.2f ms, %.0f tasks; by type C %.2f PT %.2f R %.2f RP %.2f RR %.2f ms\n",
+        fprintf(stderr, "dataflow per workgroup: waiting %.2f ms (max %.2f), bodies %.2f ms, busy max %.2f ms, %.0f tasks; by type C %.2f FP %.2f FR %.2f R %.2f RP %.2f RR %.2f ms\n",
                 w / grid / 1e5, wmax / 1e5, bd / grid / 1e5, bmax / 1e5, nn / grid, ty[0] / grid / 1e5, ty[1] / grid / 1e5, ty[2] / grid / 1e5,
-                ty[3] / grid / 1e5, ty[4] / grid / 1e5);
+                ty[3] / grid / 1e5, ty[4] / grid / 1e5, ty[5] / grid / 1e5);
     }
 #endif
     return SF_OK;
