@@ -412,9 +412,10 @@ def fill_leg(w, steps=5, warmup=2):
     torch.cuda.empty_cache()
     gbs = nbytes / (fill_ms * 1e-3) / 1e9
     probe = nbytes / (write_ms * 1e-3) / 1e9
-    traffic, src, same = pmc_lookup("fill", "k_fill_tiles")
+    traffic, src, same = pmc_lookup("fill", "k_fill_dense", total=True)
     return {
-        "kernel": "k_fill_tiles<true> via sf_cov_fill_batch: full dense C (both triangles, jitter on), row stride N",
+        "kernel": "k_fill_dense_plain + k_fill_dense_band (side by side on two streams) via sf_cov_fill_batch: full dense C "
+        "(both triangles, jitter on), row stride N",
         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
         "stream_write_probe_gbs": probe, "frac_of_stream_write_probe": gbs / probe if probe > 0 else None,
         "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": fill_ms, "transforms_ms_before_it": ms[0] / steps,
@@ -424,15 +425,17 @@ def fill_leg(w, steps=5, warmup=2):
     }
 
 
-def pmc_lookup(tag, kernel_key):
-    """(hbm bytes per launch, source file, collected-on-this-code?) of the latest profiles/r0?_*<tag>*_pmc_summary.json."""
+def pmc_lookup(tag, kernel_key, total=False):
+    """(hbm bytes per launch, source file, collected-on-this-code?) of the latest profiles/r0?_*<tag>*_pmc_summary.json;
+    total: summed over every kernel whose name starts with the key (one launch of each per step)."""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0[0-9]_*{tag}*_pmc_summary.json")))[-1:]:
         with open(f) as fh:
             summ = json.load(fh)
-        for key, val in summ.items():
-            if isinstance(val, dict) and key.lstrip("_").startswith(kernel_key) and "hbm_bytes_per_launch" in val:
-                cid = summ.get("_code_id")
-                return val["hbm_bytes_per_launch"], os.path.relpath(f, ROOT) + (f" @code {cid}" if cid else ""), (cid == code_id()) if cid else None
+        hits = [val["hbm_bytes_per_launch"] for key, val in summ.items()
+                if isinstance(val, dict) and key.lstrip("_").startswith(kernel_key) and "hbm_bytes_per_launch" in val]
+        if hits:
+            cid = summ.get("_code_id")
+            return (sum(hits) if total else hits[0]), os.path.relpath(f, ROOT) + (f" @code {cid}" if cid else ""), (cid == code_id()) if cid else None
     return None, None, None
 
 
@@ -876,9 +879,10 @@ def run(args, in_group, rank, local_rank, world, line):
             "whole_path_tflops": t["value"] * w.flops_eval / 1e12,
             "whole_path_frac_of_mfma_peak": t["value"] * w.flops_eval / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
             "roofline": {
-                "kernel": "k_chol_panel_w / k_chol_panel (fused v_mfma_f64_16x16x4_f64 panel steps of the batched Cholesky: "
-                "long-K update + triangular solves + diagonal-tile update; panel pairs when batch x slabs >= 3400, "
-                "128-column panels for the chain and smaller batches)",
+                "kernel": "k_chol_panel_w / k_chol_panel / k_potrf_dataflow (fused v_mfma_f64_16x16x4_f64 panel steps of the batched "
+                "Cholesky: long-K update + triangular solves + diagonal-tile update; panel pairs when batch x slabs >= 3400, "
+                "128-column panels for their chain and for medium batches, ONE persistent dataflow launch while batch x "
+                "panels <= 1280)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,

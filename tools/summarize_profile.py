@@ -12,7 +12,7 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 PMC_STEPS = 2
-PANEL = ("k_chol_panel", "k_gemm_nt")  # the fp64 MFMA kernels of the batched Cholesky
+PANEL = ("k_chol_panel", "k_gemm_nt", "k_potrf_dataflow")  # the fp64 MFMA kernels of the batched Cholesky
 
 
 def short(name):

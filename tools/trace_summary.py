@@ -8,7 +8,7 @@ import sys
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/trace_potrf"
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("k_diag", "k_chol_panel", "k_gemm_nt", "k_chain", "k_gate", "k_signal"))]
+idx = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("k_diag", "k_chol_panel", "k_gemm_nt", "k_potrf_dataflow"))]
 bursts, cur = [], [idx[0]]
 for a, b in zip(idx, idx[1:]):
     if int(rows[b]["Start_Timestamp"]) - int(rows[a]["End_Timestamp"]) > 2_000_000:
