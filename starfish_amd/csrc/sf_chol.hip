@@ -1162,6 +1162,11 @@ struct sf_panel_task {
     int wval;
     int* abort_flag;
     int* lds_int;  // one int of LDS for the wait's broadcast
+    int* top_flag; // dataflow chain / front task: counter set to top_val as soon as L is stored (before step 4)
+    int top_val;
+    const int* sflag;  // ... and the counter (>= sval) that says the slab's diagonal tile is ready for step 4
+    int sval;
+    long long* stamps;  // tuning builds: wall-clock stamps {K work done, diagonal tile there, L published, step 4 may start}
     int prio;
 };
 __device__ __forceinline__ sf_panel_task sf_task_of(const sf_panel_args& g) {
@@ -1183,6 +1188,11 @@ __device__ __forceinline__ sf_panel_task sf_task_of(const sf_panel_args& g) {
     q.wval = g.wval;
     q.abort_flag = g.abort_flag;
     q.lds_int = nullptr;
+    q.top_flag = nullptr;
+    q.top_val = 0;
+    q.sflag = nullptr;
+    q.sval = 0;
+    q.stamps = nullptr;
     q.prio = g.prio;
     return q;
 }
@@ -1393,15 +1403,26 @@ __device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, co
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+            // Partial tiles are stored in ACCUMULATOR order -- element (mi, ni, r) of thread t at (((mi TN + ni) 2 + r / 2) 512 + t) 2
+            // + r % 2 -- so that a lane reads its values as 16-byte loads, a wave instruction covers 1 KB, and eight loads are
+            // in flight per wait: in the tile's row-major layout hipcc (at the 128-VGPR limit, one temporary) waited for every
+            // single 8-byte load -- 256 load latencies in series, 125-180 us of the chain task's ~250 at eight partial sums.
+            const double2* P2 = (const double2*)P;
             for (int q = 0; q < tk.ksplit; ++q) {
+                const double2* Pq = P2 + (int64_t)q * (GT * GT / 2) + tid;
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
+                for (int mi = 0; mi < TM; ++mi) {
+                    double2 t[2 * TN];
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
+                    for (int j = 0; j < 2 * TN; ++j) t[j] = Pq[(mi * 2 * TN + j) * 512];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[mi][ni][r] += P[(int64_t)q * (GT * GT) + (wm * (16 * TM) + mi * 16 + lq + 4 * r) * GT +
-                                                wn * (16 * TN) + ni * 16 + l15];
+                    for (int ni = 0; ni < TN; ++ni) {
+                        acc[mi][ni][0] += t[2 * ni].x;
+                        acc[mi][ni][1] += t[2 * ni].y;
+                        acc[mi][ni][2] += t[2 * ni + 1].x;
+                        acc[mi][ni][3] += t[2 * ni + 1].y;
+                    }
+                }
             }
         } else if (MODE == 1 && sp > 0) {
 #pragma unroll
@@ -1445,6 +1466,9 @@ __device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, co
                     }
                 }
         }
+#ifdef SF_TUNING
+        if (tk.stamps && tid == 0) tk.stamps[4] = wall_clock64();  // (issue point of the last partial-sum loads)
+#endif
         gwait();
         __syncthreads();
         // (the accumulators come from compiler-counted loads: consume them here, so that hipcc places its own
@@ -1455,6 +1479,9 @@ __device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, co
             for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(acc[mi][ni][r]));
+#ifdef SF_TUNING
+        if (tk.stamps && tid == 0) tk.stamps[5] = wall_clock64();  // (partial sums added, first operand slab landed)
+#endif
         // fragment reads: lane (l15, lq) takes the two granules 2 lq, 2 lq + 1 of its row = the four consecutive
         // k = 4 lq .. 4 lq + 3; MFMA j of a slab uses element j of every lane, i.e. slice lq of instruction j stands
         // for k = 4 lq + j -- in both operands (K is a summation index)
@@ -1540,19 +1567,25 @@ __device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, co
         if (nk > 0) compute((nk - 1) & 1);
         __syncthreads();  // the epilogue re-uses the LDS with its own layouts
         if (MODE == 1) {
-            double* P = tk.part + ((int64_t)tile * tk.ksplit + sp) * (GT * GT);
+            double2* P2 = (double2*)(tk.part + ((int64_t)tile * tk.ksplit + sp) * (GT * GT)) + tid;  // (accumulator order: see MODE 2)
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        P[(wm * (16 * TM) + mi * 16 + lq + 4 * r) * GT + wn * (16 * TN) + ni * 16 + l15] = acc[mi][ni][r];
+                for (int ni = 0; ni < TN; ++ni) {
+                    P2[((mi * TN + ni) * 2 + 0) * 512] = make_double2(acc[mi][ni][0], acc[mi][ni][1]);
+                    P2[((mi * TN + ni) * 2 + 1) * 512] = make_double2(acc[mi][ni][2], acc[mi][ni][3]);
+                }
             return;
         }
 
         // (dataflow sequence: the long-K loop above did not need the diagonal tile's factor; everything below does)
+#ifdef SF_TUNING
+        if (tk.stamps && tid == 0) tk.stamps[0] = wall_clock64();
+#endif
         if (tk.wflag && !sf_df_wait(tk.wflag, tk.wval, tk.abort_flag, tid, tk.lds_int)) return;
+#ifdef SF_TUNING
+        if (tk.stamps && tid == 0) tk.stamps[1] = wall_clock64();
+#endif
         // ---------------------------------------------------------------- 2: L = T W through LDS
         const int nsb = SF_PANEL_SKIPS(g, 1) ? 0 : pw >> 4;  // 16-column blocks of the panel (4 or 8)
         const double* Wp[2];
@@ -1628,6 +1661,18 @@ __device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, co
                     if (row < rows_here && col < pw && col >= cfp) Lout[(int64_t)row * g.lda + col] = acc[mi][ni][r];
                 }
             }
+        if (tk.top_flag) {
+            // dataflow chain task: the slab's row is final HERE -- the next chain task's K work reads L, not the diagonal tile
+            // that step 4 updates and parks for this workgroup's own D(k) -- so it is published before step 4, not after it
+            __syncthreads();
+            if (tid == 0) {
+                sf_df_release();
+                sf_df_set(tk.top_flag, tk.top_val);
+#ifdef SF_TUNING
+                if (tk.stamps) tk.stamps[2] = wall_clock64();
+#endif
+            }
+        }
         if (RHS && g.rhs) {
             const double* z = g.rhs + (int64_t)b * g.ldr + k0;
             double zc[TN];
@@ -1690,6 +1735,12 @@ __device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, co
                 pa[1] = rl[q].y;
             }
         };
+        // (dataflow front tasks start on the slab's L rows; the slab's diagonal tile -- updated by the step of the previous
+        // panel, possibly still running in another workgroup -- is only needed from here on)
+        if (tk.sflag && !sf_df_wait(tk.sflag, tk.sval, tk.abort_flag, tid, tk.lds_int)) return;
+#ifdef SF_TUNING
+        if (tk.stamps && tid == 0) tk.stamps[3] = wall_clock64();
+#endif
         __syncthreads();  // the L slab is visible to every wave of the workgroup; the LDS buffers are free
         if (nk2 > 0) gload2(0);
         const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
@@ -3069,7 +3120,7 @@ struct sf_df_args {
     int nt, batch, front;
     int bq[2], ntasks[2];  // table v serves the queues with bq[v] matrices
     int pt_cap;       // largest split of the front partial sums: a (matrix, front slab) owns pt_cap tiles per panel parity in region 2
-    int *head, *abort_flag, *done_top, *done_D, *done_row, *fp_cnt, *rp_cnt, *stage_done;
+    int *head, *abort_flag, *done_top, *done_D, *done_row, *row_L, *fp_cnt, *rp_cnt, *stage_done;
     int* chain_next;  // [batch][3]: the next chain task (d = 1) / front task (d = 2, 3) of every matrix (claimed by compare-and-swap once ready)
     double* T;        // per matrix: parked diagonal tile [GT x SF_LDT], then W_k for every panel
     int64_t sT;
@@ -3128,7 +3179,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                             if (kp >= 0) {
                                 ready = sf_df_load(a.done_top + b1) >= kp;
                                 if (ready && kp >= 1) {
-                                    ready = sf_df_load(a.done_row + (size_t)b1 * nt + kp + dd) >= kp;
+                                    ready = sf_df_load(a.row_L + (size_t)b1 * nt + kp + dd) >= kp;
                                     const int St = a.st[vq][kp - 1].St;
                                     if (ready && St > 0)
                                         ready = sf_df_load(a.fp_cnt + 2 * SF_DF_FRONT_MAX * b1 + SF_DF_FRONT_MAX * (kp & 1) + dd - 1) >= a.st[vq][kp - 1].thr_pt;
@@ -3296,13 +3347,25 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 // the slab's own row left of the tail; row kp final = the FIRST half of the chain task C(b,kp) (only the solve
                 // needs its second half, the diagonal tile: this task's K work runs beside it); the partial sums
                 bool dready = false;
-                ok = sf_df_wait(kp >= 1 ? a.done_row + (size_t)b * nt + slab : nullptr, kp, a.done_top + b, kp,
+                // (own row: its L blocks left of the tail -- row_L; the slab's diagonal tile, updated by the previous panel's step
+                // for this slab, is waited for inside the body, right before step 4)
+                ok = sf_df_wait(kp >= 1 ? a.row_L + (size_t)b * nt + slab : nullptr, kp, a.done_top + b, kp,
                                 St > 0 ? fcnt + SF_DF_FRONT_MAX * (kp & 1) + d - 1 : nullptr, stp.thr_pt, a.done_D + b, kp + 1, &dready, a.abort_flag,
                                 tid, s_ints + 1);
                 if (!dready) {
                     q.wflag = a.done_D + b;
                     q.wval = kp + 1;
                 }
+                if (kp >= 1) {
+                    q.sflag = a.done_row + (size_t)b * nt + slab;
+                    q.sval = kp;
+                }
+                // (the row is published from inside the body, as soon as L is stored: the chain's row counter / the slab's row_L)
+                q.top_flag = type == T_C ? a.done_top + b : a.row_L + (size_t)b * nt + slab;
+                q.top_val = type == T_C ? k : kp + 1;
+#ifdef SF_TUNING
+                if (a.dbg && b == 0 && type == T_C && k < 64) q.stamps = a.dbg + 10 * SF_CHIP_WGS + 16 * 64 + 8 * k;
+#endif
                 SF_DF_MARK();
                 if (ok) sf_panel_body<RHS, 3>(g, q, b, sm, red, tid);
             }
@@ -3318,9 +3381,13 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
 #ifdef SF_TUNING
                 dbg_top = wall_clock64();
 #endif
-                if (tid == 0) {  // row k is final through panel k-1; the parked tile must be re-read through the L2
-                    sf_df_release();
-                    sf_df_set(a.done_top + b, k);
+                if (tid == 0) {  // the parked tile must be re-read through the L2 (k = 0: nothing was published from the body)
+                    if (k == 0) {
+                        sf_df_release();
+                        sf_df_set(a.done_top + b, k);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
@@ -3402,6 +3469,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     if (type == T_RP) {
                         sf_df_add(a.rp_cnt + (size_t)b * nt + i, 1);
                     } else {
+                        sf_df_set(a.row_L + (size_t)b * nt + i, k + 1);
                         sf_df_set(rowflag, k + 1);
                         if (type == T_RR) sf_df_add(sdone + k, 1);
                     }
@@ -3462,8 +3530,8 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     const int nt = (n + GT - 1) / GT;
     // counters: in the two inverse-tile buffers of the launch sequences (2 x batch x sW doubles), which this sequence does not use
     int* flags = (int*)Wt2;
-    const size_t ndbg = 2 * (10 * SF_CHIP_WGS + 16 * 64);
-    const size_t nflags = 64 + (size_t)batch * (2 * nt + 2 + 3 * SF_DF_FRONT_MAX) + (size_t)SF_DF_QUEUES * nt + 8 + ndbg;
+    const size_t ndbg = 2 * (10 * SF_CHIP_WGS + 16 * 64 + 8 * 64);
+    const size_t nflags = 64 + (size_t)batch * (3 * nt + 2 + 3 * SF_DF_FRONT_MAX) + (size_t)SF_DF_QUEUES * nt + 8 + ndbg;
     if (nt - 1 > SF_DF_MAX_STAGES || nflags * sizeof(int) > 2 * (size_t)batch * sW * sizeof(double)) {
         sf_set_error("potrf: dataflow sequence: %d panels / %d matrices do not fit its tables", nt, batch);
         return SF_EINVAL;
@@ -3476,7 +3544,8 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.chain_next = a.done_D + batch;
     a.fp_cnt = a.chain_next + SF_DF_FRONT_MAX * batch;  // [batch][2][SF_DF_FRONT_MAX]
     a.done_row = a.fp_cnt + 2 * SF_DF_FRONT_MAX * batch;      // [batch][nt]
-    a.rp_cnt = a.done_row + (size_t)batch * nt;
+    a.row_L = a.done_row + (size_t)batch * nt;
+    a.rp_cnt = a.row_L + (size_t)batch * nt;
     a.stage_done = a.rp_cnt + (size_t)batch * nt;  // [SF_DF_QUEUES][nt]
     SF_HIP(hipMemsetAsync(flags, 0, nflags * sizeof(int), s));
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
@@ -3505,10 +3574,10 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     }
     // front width: the rows the chain needs next must be a reduce-and-epilogue behind it, and the first ORDINARY slab of a
     // stage (a long-K task, or partial sums + reduce) gets `front` chain periods before the front needs its row.  Front tasks
-    // cost more than ordinary ones (partial sums written and read back).  N = 4096, front 1 / 2 / 3 / 4 / 5 / 6: B = 16 8.95 /
-    // 8.85 / 8.85 / 8.95 / 8.5 / 8.45 ms, B = 32 14.7 / 14.65 / 14.8 / 14.85 / 14.85 / 15.05, B = 48 20.3 / 20.5 / 20.8 / 21.3 / 21.5 / 22.2
+    // cost more than ordinary ones (partial sums written and read back).  N = 4096, front 1 / 2 / 3 / 4 / 6: B = 16 8.1 / 8.0 /
+    // 7.87 / 7.84 / 7.85 ms, B = 32 13.7 / 13.8 / 13.7 / 13.9 / 14.6, B = 64 25.45 / 25.7 / 26.3 / 26.85 / 28.0
     static const int front_env = SF_TUNE_INT("SF_DF_FRONT", 0);
-    const int F = std::max(1, std::min(SF_DF_FRONT_MAX, front_env > 0 ? front_env : (batch <= 20 ? 6 : 2)));
+    const int F = std::max(1, std::min(SF_DF_FRONT_MAX, front_env > 0 ? front_env : (batch <= 20 ? 3 : 1)));
     a.front = F;
     a.nt = nt;
     a.batch = batch;
@@ -3595,7 +3664,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     SF_LAUNCH_CHECK();
 #ifdef SF_TUNING
     if (a.dbg) {
-        static long long host[10 * SF_CHIP_WGS + 16 * 64];
+        static long long host[10 * SF_CHIP_WGS + 16 * 64 + 8 * 64];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(host, a.dbg, sizeof(host), hipMemcpyDeviceToHost);
         double w = 0, bd = 0, nn = 0, ty[6] = {0, 0, 0, 0, 0, 0};
@@ -3615,7 +3684,11 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
             for (int k = 0; k < nt && k < 64; ++k) {
                 fprintf(stderr, "%2d |", k);
                 for (int j = 0; j < 12; ++j) fprintf(stderr, "%s%8.1f", j % 3 == 0 && j ? " |" : "", tr[16 * k + j] ? (tr[16 * k + j] - t0) / 100.0 : 0.0);
-                fprintf(stderr, " | C: panel part %6.1f, D %6.1f\n", (tr[16 * k + 12] - tr[16 * k + 1]) / 100.0, (tr[16 * k + 2] - tr[16 * k + 12]) / 100.0);
+                const long long* st4 = host + 10 * SF_CHIP_WGS + 16 * 64 + 8 * k;
+                fprintf(stderr, " | C: reduce %6.1f + tail %6.1f", (st4[5] - tr[16 * k + 1]) / 100.0, (st4[0] - st4[5]) / 100.0);
+                fprintf(stderr, " | C: K work %6.1f, wait D %6.1f, solve+store %6.1f, wait S %6.1f, step 4 %6.1f, D %6.1f\n",
+                        (st4[0] - tr[16 * k + 1]) / 100.0, (st4[1] - st4[0]) / 100.0, (st4[2] - st4[1]) / 100.0, (st4[3] - st4[2]) / 100.0,
+                        (tr[16 * k + 12] - st4[3]) / 100.0, (tr[16 * k + 2] - tr[16 * k + 12]) / 100.0);
             }
         }
         fprintf(stderr, "dataflow per workgroup: waiting %.2f ms (max %.2f), bodies %.2f ms, busy max %.2f ms, %.0f tasks; by type C %.2f FP %.2f FR %.2f R %.2f RP %.2f RR %.2f ms\n",
@@ -3631,14 +3704,15 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
 // B = 12: 10.0 / 9.05-9.6 ms, 16: 10.97 / 11.1, 20: 12.2 / 12.6, 24: 13.3 / 13.9, 32: 15.4 / 16.9, 64: 26.1 / 29.5.
 #define SF_UNFUSED_BELOW 16
 // The dataflow sequence (one persistent launch) wins wherever the launch sequences cannot keep the chip full between their
-// panel boundaries.  Measured (tools/bench_potrf.py, same box, launch sequences / dataflow): N = 4096: B = 4 6.5 / 6.0 ms,
-// 8: 7.4 / 6.4, 12: 8.8 / 8.5, 16: 10.3 / 8.7, 24: 12.7 / 12.1, 32: 15.0 / 14.7, 48: 20.7 / 20.7, 64: 26.0 / 26.5, 128: 49.3
-// (wide: 47.0) / 51.1; N = 3008: B = 16 6.15 / 4.74, 64: 11.8 / 12.3; N = 2048: B = 16 3.36 / 2.50, 64: 5.22 / 5.02;
-// N = 1024: B = 16 1.29 / 0.88, 64: 1.51 / 1.40  ->  taken while batch x panels <= 1280.
+// panel boundaries.  Measured (tools/bench_potrf.py, same box, launch sequences (fused; wide where it is their choice) /
+// dataflow): N = 4096: B = 8 7.4 / 5.1 ms, 16: 9.6 / 7.85, 32: 14.2 / 13.7, 48: 20.0 / 19.9, 64: 25.9 / 25.45, 80: 31.9 / 32.1,
+// 96: 37.5 / 38.3, 112: 42.4 / 44.4, 128: 47.1 / 50.7; N = 3008: B = 16 6.15 / 4.7, 64: 11.8 / 11.5, 96: 16.7 / 16.9; N = 2048:
+// B = 16 3.36 / 2.5, 128: 8.15 / 8.1; N = 1024: B = 16 1.29 / 0.88, 256: 2.8 / 3.2 (32 matrices per queue: the dispenser's scan
+// of their chain counters shows)  ->  taken while batch x panels <= 2048 and batch <= 128.
 static bool sf_potrf_dataflow_auto(int n, int batch) {
-    static const int lim = SF_TUNE_INT("SF_DF_BELOW", 1280);
+    static const int lim = SF_TUNE_INT("SF_DF_BELOW", 2048);
     const int nt = (n + 64 + GT - 1) / GT;  // (panels of the shifted frame at most)
-    return nt - 1 <= SF_DF_MAX_STAGES && (long long)batch * nt <= lim;
+    return nt - 1 <= SF_DF_MAX_STAGES && (long long)batch * nt <= lim && batch <= 128;
 }
 int sf_potrf_front_pad(int n, int batch) {
     static const bool off = SF_TUNE_FLAG("SF_NO_FRONT_PAD");  // tuning aid: A/B of the shifted frame

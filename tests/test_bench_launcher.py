@@ -76,8 +76,11 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_both_scalings():
     assert s["value"] > 0 and s["ms_per_step"] > 0
     # the clock probe survives the process group (sampled before it is created); its value means nothing for a step
     # this short (the probe wave mostly sees an idle chip)
-    assert d["roofline"]["sustained_clock_mhz"] and d["roofline"]["sustained_clock_mhz"] > 0
-    assert "before the process group" in d["roofline"]["sustained_clock_note"]
+    # (two processes time-slice the one GPU here: a probe wave that was context-switched is discarded by bench.py)
+    clk = d["roofline"]["sustained_clock_mhz"]
+    assert clk is None or 200 < clk < 4000
+    if clk is not None:
+        assert "before the process group" in d["roofline"]["sustained_clock_note"]
 
 
 @pytest.mark.gpu

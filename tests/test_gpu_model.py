@@ -449,7 +449,7 @@ def test_paper_form_of_the_emulator_covariance_is_a_non_default_switch():
     assert out["info"][0] == 0 and close_lnl(out["lnl"][0], O.log_likelihood(oo, pp))
     md0, rows0 = pack_rows(do, [base])
     assert close_lnl(do.loglike(md0, rows0)["lnl"][0], g["full_lnl"][0])
-    assert not np.isclose(out["lnl"][0], g["full_lnl"][0], rtol=1e-6)
+    assert abs(out["lnl"][0] - g["full_lnl"][0]) > 1e-4  # (the two forms really differ: 1e-3 here, far above the 1e-8 tolerance)
     # through the product API
     m_code = synth.build_model(o)
     m_paper = synth.build_model(o, emulator_cov="paper")
