@@ -1745,16 +1745,30 @@ __device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, co
         if (nk2 > 0) gload2(0);
         const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
         sf_d4 acc2[5];
+        // (full slabs -- all but the last of a matrix whose order is not a multiple of 128 -- take straight-line loads and
+        // stores: behind per-element predicates hipcc put every access into a block of its own and waited for it there,
+        // twenty load and eighteen store latencies in series per task)
+        const bool full_tile = rows_here == GT && row0 >= g.fp;
+        if (full_tile) {
 #pragma unroll
-        for (int q = 0; q < 5; ++q)
+            for (int q = 0; q < 5; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
-                if (row0 + min(row, col) < g.fp)  // virtual rows / columns of the first tile: identity
-                    acc2[q][r] = row == col ? 1.0 : 0.0;
-                else
-                    acc2[q][r] = (q < nstore && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
+                    acc2[q][r] = Sin[(int64_t)row * g.lda + col];  // (wave pairs with four blocks read a fifth one they never store)
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
+                    if (row0 + min(row, col) < g.fp)  // virtual rows / columns of the first tile: identity
+                        acc2[q][r] = row == col ? 1.0 : 0.0;
+                    else
+                        acc2[q][r] = (q < nstore && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
+                }
+        }
         if (nk2 > 0) lstore2(0);
         __syncthreads();
         auto compute2 = [&](int cur) {
@@ -1777,13 +1791,30 @@ __device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, co
         const bool parked = tk.Sout && sl == 0;  // (only the first slab of a launch is the next diagonal tile)
         double* So = parked ? tk.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
         const int ldo = parked ? g.ldS : g.lda;
+        if (full_tile) {
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            if (q >= nstore) continue;
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
-                if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[q][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
+                    So[(int64_t)row * ldo + col] = acc2[q][r];
+                }
+            if (nstore == 5) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bi[4] + lq + 4 * r, col = 16 * bj[4] + l15;
+                    So[(int64_t)row * ldo + col] = acc2[4][r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                if (q >= nstore) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bi[q] + lq + 4 * r, col = 16 * bj[q] + l15;
+                    if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[q][r];
+                }
             }
         }
     }
