@@ -2202,13 +2202,23 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
         sf_d4 acc2[3];
         {
             const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
+            if (rows_here == GT) {  // (full slab: straight-line loads -- see k_chol_panel, step 4)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
-                    acc2[j][r] = (j < nsb && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
+                        acc2[j][r] = Sin[(int64_t)row * g.lda + col];  // (a wave with two blocks reads a third one it never stores)
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
+                        acc2[j][r] = (j < nsb && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
+                    }
+            }
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -2234,13 +2244,30 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
         const bool parked = g.Sout && sl == 0;  // (only the first slab of a launch is the next diagonal tile)
         double* So = parked ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
         const int ldo = parked ? g.ldS : g.lda;
+        if (rows_here == GT) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (j >= nsb) continue;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
-                if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[j][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
+                    So[(int64_t)row * ldo + col] = acc2[j][r];
+                }
+            if (nsb == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * sbi[2] + lq + 4 * r, col = 16 * sbj[2] + l15;
+                    So[(int64_t)row * ldo + col] = acc2[2][r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j >= nsb) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
+                    if (row < rows_here && col < rows_here) So[(int64_t)row * ldo + col] = acc2[j][r];
+                }
             }
         }
     }
@@ -3712,7 +3739,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
             const long long* tr = host + 10 * SF_CHIP_WGS;
             long long t0 = tr[0];
             fprintf(stderr, "matrix 0, us since its first task: k | C claim start end | FP(k,1) claim start end | FP(k,2) claim start end | FR(k,2) claim start end\n");
-            for (int k = 0; k < nt && k < 64; ++k) {
+            for (int k = 1; k < nt && k < 64; ++k) {  // (k = 0 has no panel part)
                 fprintf(stderr, "%2d |", k);
                 for (int j = 0; j < 12; ++j) fprintf(stderr, "%s%8.1f", j % 3 == 0 && j ? " |" : "", tr[16 * k + j] ? (tr[16 * k + j] - t0) / 100.0 : 0.0);
                 const long long* st4 = host + 10 * SF_CHIP_WGS + 16 * 64 + 8 * k;
