@@ -3176,6 +3176,7 @@ __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy
 struct sf_df_args {
     sf_panel_args p;  // matrix, right-hand side, generator, frame: the per-task fields are filled in by the kernel
     int nt, batch, front;
+    int fp_pos;       // position of the front partial sums inside a stage's segment, in 1/256 of its rest tasks
     int bq[2], ntasks[2];  // table v serves the queues with bq[v] matrices
     int pt_cap;       // largest split of the front partial sums: a (matrix, front slab) owns pt_cap tiles per panel parity in region 2
     int *head, *abort_flag, *done_top, *done_D, *done_row, *row_L, *fp_cnt, *rp_cnt, *stage_done;
@@ -3319,8 +3320,14 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
             const int nord = max(0, nt - kst - 1 - F);
             const int n_fp = B * nF * st.St;
             const int n_r1 = B * nord * (st.Sr > 1 ? st.Sr : 1);
+            // segment: fp_pos/256 of the rest tasks, the front partial sums of the NEXT panel, the other rest tasks, the reduces.
+            // (FP tasks at the very front of the segment are claimed while the two rows they read are still being finished by
+            // tasks of the previous stage: with many matrices per queue -- the chain is not what the rest waits for -- they
+            // come later: 1.1 of 1.95 ms of waiting per workgroup at 32 matrices was theirs)
+            const int n_r0 = (int)(((long long)n_r1 * a.fp_pos) >> 8);
             int u = t - st.off;
-            if (u < n_fp) {
+            if (u >= n_r0 && u < n_r0 + n_fp) {
+                u -= n_r0;
                 type = T_FP;
                 k = kst + 1;
                 S = st.St;
@@ -3329,7 +3336,8 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 bl = u / S;
                 sp = u - bl * S;
                 i = k + d;
-            } else if ((u -= n_fp) < n_r1) {
+            } else if (u < n_r1 + n_fp) {
+                if (u >= n_r0) u -= n_fp;
                 k = kst;
                 S = st.Sr;
                 type = S > 1 ? T_RP : T_R;
@@ -3338,7 +3346,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 bl = tile / nord;
                 i = k + 1 + F + (tile - bl * nord);
             } else {
-                u -= n_r1;
+                u -= n_r1 + n_fp;
                 k = kst;
                 S = st.Sr;
                 type = T_RR;
@@ -3422,7 +3430,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 q.top_flag = type == T_C ? a.done_top + b : a.row_L + (size_t)b * nt + slab;
                 q.top_val = type == T_C ? k : kp + 1;
 #ifdef SF_TUNING
-                if (a.dbg && b == 0 && type == T_C && k < 64) q.stamps = a.dbg + 10 * SF_CHIP_WGS + 16 * 64 + 8 * k;
+                if (a.dbg && b == 0 && type == T_C && k < 64) q.stamps = a.dbg + 16 * SF_CHIP_WGS + 16 * 64 + 8 * k;
 #endif
                 SF_DF_MARK();
                 if (ok) sf_panel_body<RHS, 3>(g, q, b, sm, red, tid);
@@ -3539,13 +3547,14 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
 #ifdef SF_TUNING
         if (a.dbg && tid == 0) {
             const long long t2 = wall_clock64();
-            long long* dd = a.dbg + 10 * (size_t)blockIdx.x;
+            long long* dd = a.dbg + 16 * (size_t)blockIdx.x;
             dd[0] += dbg_t1 - dbg_t0;
             dd[1] += t2 - dbg_t1;
             dd[2] += 1;
             dd[3 + type] += t2 - dbg_t0;
+            dd[9 + type] += dbg_t1 - dbg_t0;
             if (b == 0 && k < 64) {  // timeline of matrix 0: chain task, its partial sums, the front slab d = 2
-                long long* tr = a.dbg + 10 * SF_CHIP_WGS + 16 * k;
+                long long* tr = a.dbg + 16 * SF_CHIP_WGS + 16 * k;
                 const int slot = type == T_C ? 0 : (type == T_FP && d == 1 && sp == 0) ? 3 : (type == T_FP && d == 2 && sp == 0) ? 6 : (type == T_FR && d == 2) ? 9 : -1;
                 if (slot >= 0) {
                     tr[slot] = dbg_t0;
@@ -3588,7 +3597,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     const int nt = (n + GT - 1) / GT;
     // counters: in the two inverse-tile buffers of the launch sequences (2 x batch x sW doubles), which this sequence does not use
     int* flags = (int*)Wt2;
-    const size_t ndbg = 2 * (10 * SF_CHIP_WGS + 16 * 64 + 8 * 64);
+    const size_t ndbg = 2 * (16 * SF_CHIP_WGS + 16 * 64 + 8 * 64);
     const size_t nflags = 64 + (size_t)batch * (3 * nt + 2 + 3 * SF_DF_FRONT_MAX) + (size_t)SF_DF_QUEUES * nt + 8 + ndbg;
     if (nt - 1 > SF_DF_MAX_STAGES || nflags * sizeof(int) > 2 * (size_t)batch * sW * sizeof(double)) {
         sf_set_error("potrf: dataflow sequence: %d panels / %d matrices do not fit its tables", nt, batch);
@@ -3637,6 +3646,8 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     static const int front_env = SF_TUNE_INT("SF_DF_FRONT", 0);
     const int F = std::max(1, std::min(SF_DF_FRONT_MAX, front_env > 0 ? front_env : (batch <= 20 ? 3 : 1)));
     a.front = F;
+    static const int fp_pos_env = SF_TUNE_INT("SF_DF_FP_POS", -1);
+    a.fp_pos = fp_pos_env >= 0 ? fp_pos_env : 256;  // (0 / 64 / 128 / 192 / 256: B = 16 7.75 / 7.7 / 7.6 / 7.7 / 7.55 ms, B = 32 13.8 / 13.9 / 13.75 / 13.7 / 13.65)
     a.nt = nt;
     a.batch = batch;
     a.T = T;
@@ -3722,27 +3733,28 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     SF_LAUNCH_CHECK();
 #ifdef SF_TUNING
     if (a.dbg) {
-        static long long host[10 * SF_CHIP_WGS + 16 * 64 + 8 * 64];
+        static long long host[16 * SF_CHIP_WGS + 16 * 64 + 8 * 64];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(host, a.dbg, sizeof(host), hipMemcpyDeviceToHost);
-        double w = 0, bd = 0, nn = 0, ty[6] = {0, 0, 0, 0, 0, 0};
+        double w = 0, bd = 0, nn = 0, ty[6] = {0, 0, 0, 0, 0, 0}, tw[6] = {0, 0, 0, 0, 0, 0};
         long long wmax = 0, bmax = 0;
         for (int i = 0; i < grid; ++i) {
-            w += host[10 * i];
-            bd += host[10 * i + 1];
-            nn += host[10 * i + 2];
-            for (int j = 0; j < 6; ++j) ty[j] += host[10 * i + 3 + j];
-            wmax = std::max(wmax, host[10 * i]);
-            bmax = std::max(bmax, host[10 * i] + host[10 * i + 1]);
+            w += host[16 * i];
+            bd += host[16 * i + 1];
+            nn += host[16 * i + 2];
+            for (int j = 0; j < 6; ++j) ty[j] += host[16 * i + 3 + j];
+            for (int j = 0; j < 6; ++j) tw[j] += host[16 * i + 9 + j];
+            wmax = std::max(wmax, host[16 * i]);
+            bmax = std::max(bmax, host[16 * i] + host[16 * i + 1]);
         }
         if (SF_TUNE_FLAG("SF_DF_TRACE")) {
-            const long long* tr = host + 10 * SF_CHIP_WGS;
+            const long long* tr = host + 16 * SF_CHIP_WGS;
             long long t0 = tr[0];
             fprintf(stderr, "matrix 0, us since its first task: k | C claim start end | FP(k,1) claim start end | FP(k,2) claim start end | FR(k,2) claim start end\n");
             for (int k = 1; k < nt && k < 64; ++k) {  // (k = 0 has no panel part)
                 fprintf(stderr, "%2d |", k);
                 for (int j = 0; j < 12; ++j) fprintf(stderr, "%s%8.1f", j % 3 == 0 && j ? " |" : "", tr[16 * k + j] ? (tr[16 * k + j] - t0) / 100.0 : 0.0);
-                const long long* st4 = host + 10 * SF_CHIP_WGS + 16 * 64 + 8 * k;
+                const long long* st4 = host + 16 * SF_CHIP_WGS + 16 * 64 + 8 * k;
                 fprintf(stderr, " | C: reduce %6.1f + tail %6.1f", (st4[5] - tr[16 * k + 1]) / 100.0, (st4[0] - st4[5]) / 100.0);
                 fprintf(stderr, " | C: K work %6.1f, wait D %6.1f, solve+store %6.1f, wait S %6.1f, step 4 %6.1f, D %6.1f\n",
                         (st4[0] - tr[16 * k + 1]) / 100.0, (st4[1] - st4[0]) / 100.0, (st4[2] - st4[1]) / 100.0, (st4[3] - st4[2]) / 100.0,
@@ -3752,6 +3764,8 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
         fprintf(stderr, "dataflow per workgroup: waiting %.2f ms (max %.2f), bodies %.2f ms, busy max %.2f ms, %.0f tasks; by type C %.2f FP %.2f FR %.2f R %.2f RP %.2f RR %.2f ms\n",
                 w / grid / 1e5, wmax / 1e5, bd / grid / 1e5, bmax / 1e5, nn / grid, ty[0] / grid / 1e5, ty[1] / grid / 1e5, ty[2] / grid / 1e5,
                 ty[3] / grid / 1e5, ty[4] / grid / 1e5, ty[5] / grid / 1e5);
+        fprintf(stderr, "dataflow waiting by type: C %.2f FP %.2f FR %.2f R %.2f RP %.2f RR %.2f ms\n", tw[0] / grid / 1e5, tw[1] / grid / 1e5,
+                tw[2] / grid / 1e5, tw[3] / grid / 1e5, tw[4] / grid / 1e5, tw[5] / grid / 1e5);
     }
 #endif
     return SF_OK;
