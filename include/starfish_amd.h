@@ -326,12 +326,14 @@ int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, const doubl
                           double* d_A, int npad, int lda, void* stream);
 
 /* Tuning / test aid (process-global): the batched Cholesky has three launch sequences -- the fused panel kernel
- * (128-column panels, two workgroups per CU; the default once the batch fills the chip), the unfused one (256-column
- * panels, separate panel-solve and diagonal-update launches; fewer sequential steps, taken for batches below 16
- * matrices) and the wide one (pairs of panels, one 16-wave workgroup per CU keeps a 128 x 256 tile: a third less HBM
+ * (128-column panels, two workgroups per CU; medium batches), the unfused one (256-column panels, separate panel-solve and
+ * diagonal-update launches; kept selectable) and the wide one (pairs of panels, one 16-wave workgroup per CU keeps a 128 x 256 tile: a third less HBM
  * traffic; taken when batch x 128-row slabs >= 3400 and the matrices have 2048 or more rows).
  * mode -1 = choose by batch and matrix size (default), 0 = always fused, 1 = always unfused, 2 = always wide,
- * 3 = wide for the first half of the panels, then fused (test aid: exercises the hand-over between the two).
+ * 3 = wide for the first half of the panels, then fused (test aid: exercises the hand-over between the two),
+ * 4 = dataflow: the whole factorisation as ONE persistent launch whose workgroups draw tasks and wait on exactly the tasks
+ * they depend on (the default while batch x 128-column panels <= 2048 and batch <= 128; matrices of more than 65 panels take
+ * the fused sequence instead).
  * The fused and wide sequences factorise matrices of 64 mod 128 rows in a frame shifted by 64 virtual identity rows
  * (addressing only: nothing moves in memory, the caller's layout and the pivot index reported in d_info are unchanged).
  * Same results to rounding. */
