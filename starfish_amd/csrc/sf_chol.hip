@@ -1239,6 +1239,15 @@ __device__ __forceinline__ void sf_solve_step(sf_d4 (&acc)[2][4], const double* 
 __device__ __forceinline__ int sf_df_load(const int* flag) {
     return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the waiter that raises the abort flag leaves what it was waiting for behind it: abort_flag[1..] = {counter (offset from the abort
+// flag, in ints), target, value} of the first counter that had not arrived (tuning builds print it)
+__device__ __forceinline__ void sf_df_report(int* abort_flag, const int* f, int target) {
+    if (__hip_atomic_exchange(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && f) {
+        abort_flag[1] = (int)(f - abort_flag);
+        abort_flag[2] = target;
+        abort_flag[3] = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 // Waits until *f1 >= t1 and *f2 >= t2 and *f3 >= t3 (NULL flags are skipped), then ONE acquire for all of them.  `probe`
 // (optional) is only looked at, before the acquire: *probe_ok tells whether it had reached its target -- the data it guards
 // is then covered by this acquire and needs no wait of its own later.  Returns false when the launch is being aborted.
@@ -1249,6 +1258,8 @@ __device__ __forceinline__ bool sf_df_wait(const int* f1, int t1, const int* f2,
                                            int* s_okp) {
     if (tid == 0) {
         int ok = 1;
+        // (short-circuit on purpose: a poller asks for the first counter that is missing only -- polls of all three, every
+        // time, from a few hundred waiting workgroups slowed the launch by 2 %)
         auto ready = [&]() {
             return (!f1 || sf_df_load(f1) >= t1) && (!f2 || sf_df_load(f2) >= t2) && (!f3 || sf_df_load(f3) >= t3);
         };
@@ -1259,8 +1270,13 @@ __device__ __forceinline__ bool sf_df_wait(const int* f1, int t1, const int* f2,
                 __builtin_amdgcn_s_sleep(4);
                 if (ready()) break;
                 if ((++it & 31) == 0) {
-                    if (sf_df_load(abort_flag) != 0 || wall_clock64() - t0 > SF_DF_TIMEOUT_TICKS) {
-                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sf_df_load(abort_flag) != 0) {
+                        ok = 0;
+                        break;
+                    }
+                    if (wall_clock64() - t0 > SF_DF_TIMEOUT_TICKS) {
+                        const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
+                        sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3));
                         ok = 0;
                         break;
                     }
@@ -3186,6 +3202,8 @@ struct sf_df_args {
     double* part;     // three regions of sf_split_region_tiles() tiles: rest partial sums by stage parity, front partial sums
     int* info;
     long long* dbg;   // tuning builds: per workgroup {ticks waiting, ticks in task bodies, tasks, ticks by type} (100 MHz)
+    long long* trace; // tuning builds (SF_DF_TRACE_FILE): [0] = records written, then {type | k << 8 | i << 16 | b << 24 | workgroup << 40, claimed, body start, end}
+    long long trace_cap;
     sf_df_stage st[2][SF_DF_MAX_STAGES];
 };
 #define SF_DF_LDS_DOUBLES ((37 * DBS + 128) > (4 * GT * GLD + 2 * GT) ? (37 * DBS + 128) : (4 * GT * GLD + 2 * GT))
@@ -3210,6 +3228,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
     int qcur = (int)(blockIdx.x & (SF_DF_QUEUES - 1));
     int visited = 0;
     int kst = 0;  // stage hint: a workgroup draws the tasks of a queue in increasing order
+    if (threadIdx.x == 0) s_ints[5] = 0;  // (idle spell of the end-of-launch phase, see the dispenser)
     for (;;) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -3220,6 +3239,13 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
         const int v = B == a.bq[0] ? 0 : 1;
         const int ntasks = B > 0 ? a.ntasks[v] : 0;
         // ---- dispenser.  Chain tasks first, then the queue of this workgroup's XCD, then the other queues.
+        // (A claim can be missed: two workgroups that complete the last two dependencies of a chain task within a store's flight
+        // time of each other may both read the other's counter too early and both find the task not ready.  The next
+        // workgroup of the queue that passes here claims it, a few us later; if every workgroup of the queue sits in a wait
+        // by then, the workgroups of the other queues do at the end of the launch, when each looks at every chain.  Measured
+        // and not taken: waiting for this workgroup's counter stores to be acknowledged before the scan (2 % of a launch),
+        // one lane per candidate instead of one lane walking the matrices (claims cost 20 instead of 28 us, launches of 8-32
+        // matrices ran 2-5 % slower), waits that give up after 20 us to serve the chains and come back (3-14 % slower).)
         if (tid == 0) {
             int t = -1, cb = 0, ck = 0, cd = 1;
             if (sf_df_load(a.abort_flag) == 0) {
@@ -3266,15 +3292,29 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     // every queue is exhausted: help the chains that are still running, leave when none is
                     bool live = false;
                     for (int qx = 0; qx < SF_DF_QUEUES && t == -2; ++qx)
-                        if (try_chain(qx)) t = -3;
+                        if (try_chain(qx)) {
+                            t = -3;
+                            s_ints[5] = 0;
+                        }
                     if (t == -2) {
                         for (int b1 = 0; b1 < a.batch; ++b1) {
                             live = live || sf_df_load(a.chain_next + SF_DF_FRONT_MAX * b1) < nt;
                             for (int dd = 2; dd <= F; ++dd)
                                 live = live || sf_df_load(a.chain_next + SF_DF_FRONT_MAX * b1 + dd - 1) + dd <= nt - 1;
                         }
-                        if (!live) t = -5;
-                        else __builtin_amdgcn_s_sleep(64);
+                        if (!live) {
+                            t = -5;
+                        } else {
+                            // (bounded like every wait: chains that stay open with nothing left to run them would spin here for ever)
+                            // (s_ints[5]: the 10.5 ms unit of the wall clock at which this idle spell began, + 1; 0 = none)
+                            const int now = (int)((wall_clock64() >> 20) & 0x3fffffff) + 1;
+                            if (s_ints[5] == 0) s_ints[5] = now;
+                            if (((now - s_ints[5]) & 0x3fffffff) > (int)(SF_DF_TIMEOUT_TICKS >> 20)) {
+                                sf_df_report(a.abort_flag, a.chain_next, nt);
+                                t = -1;
+                            }
+                            __builtin_amdgcn_s_sleep(64);
+                        }
                     }
                 }
             }
@@ -3553,6 +3593,16 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
             dd[2] += 1;
             dd[3 + type] += t2 - dbg_t0;
             dd[9 + type] += dbg_t1 - dbg_t0;
+            if (a.trace) {
+                const long long slot = (long long)atomicAdd((unsigned long long*)a.trace, 1ull);
+                if (slot < a.trace_cap) {
+                    long long* r = a.trace + 4 + 4 * slot;
+                    r[0] = (long long)type | ((long long)k << 8) | ((long long)i << 16) | ((long long)b << 24) | ((long long)blockIdx.x << 40);
+                    r[1] = dbg_t0;
+                    r[2] = dbg_t1;
+                    r[3] = t2;
+                }
+            }
             if (b == 0 && k < 64) {  // timeline of matrix 0: chain task, its partial sums, the front slab d = 2
                 long long* tr = a.dbg + 16 * SF_CHIP_WGS + 16 * k;
                 const int slot = type == T_C ? 0 : (type == T_FP && d == 1 && sp == 0) ? 3 : (type == T_FP && d == 2 && sp == 0) ? 6 : (type == T_FR && d == 2) ? 9 : -1;
@@ -3656,6 +3706,12 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.info = info;
 #ifdef SF_TUNING
     if (SF_TUNE_FLAG("SF_DF_VERBOSE")) a.dbg = (long long*)(flags + ((nflags - ndbg + 1) & ~(size_t)1));
+    static const char* trace_file = SF_TUNE_STR("SF_DF_TRACE_FILE");  // every task's {what, claimed, body start, end} as text
+    if (trace_file && a.dbg) {
+        a.trace_cap = 1 << 18;
+        SF_HIP(hipMalloc((void**)&a.trace, sizeof(long long) * (4 + 4 * (size_t)a.trace_cap)));
+        SF_HIP(hipMemsetAsync(a.trace, 0, sizeof(long long) * 4, s));
+    }
 #endif
 
     // ---- the task tables: one per queue size (ceil and floor of batch / 8)
@@ -3732,6 +3788,36 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     sf_prof_gemm_end(tok);
     SF_LAUNCH_CHECK();
 #ifdef SF_TUNING
+    if (SF_TUNE_FLAG("SF_DF_CHECK")) {  // which wait timed out?  (synchronises)
+        int ab[4];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(ab, a.abort_flag, sizeof(ab), hipMemcpyDeviceToHost);
+        if (ab[0]) {
+            const long off = ab[1] + 32;  // offset from `flags`
+            const long o_top = 64, o_D = o_top + batch, o_cn = o_D + batch, o_fp = o_cn + SF_DF_FRONT_MAX * batch, o_row = o_fp + 2 * SF_DF_FRONT_MAX * batch,
+                       o_L = o_row + (long)batch * nt, o_rp = o_L + (long)batch * nt, o_sd = o_rp + (long)batch * nt;
+            const char* what = off >= o_sd ? "stage_done[q][k]" : off >= o_rp ? "rp_cnt[b][i]" : off >= o_L ? "row_L[b][i]" : off >= o_row ? "done_row[b][i]" :
+                               off >= o_fp ? "fp_cnt[b][parity][d]" : off >= o_cn ? "chain_next" : off >= o_D ? "done_D[b]" : "done_top[b]";
+            const long base = off >= o_sd ? o_sd : off >= o_rp ? o_rp : off >= o_L ? o_L : off >= o_row ? o_row : off >= o_fp ? o_fp : off >= o_cn ? o_cn : off >= o_D ? o_D : o_top;
+            const long rel = off - base, per = off >= o_sd ? nt : off >= o_rp ? nt : off >= o_row ? nt : off >= o_fp ? 2 * SF_DF_FRONT_MAX : 1;
+            fprintf(stderr, "dataflow ABORTED (n=%d batch=%d front=%d): a wait for %s index %ld / %ld (target %d, value %d) timed out\n", n, batch, F, what,
+                    rel / per, rel % per, ab[2], ab[3]);
+            std::vector<int> fl(nflags - ndbg);
+            (void)hipMemcpy(fl.data(), flags, sizeof(int) * fl.size(), hipMemcpyDeviceToHost);
+            for (int bb = 0; bb < batch; ++bb) {
+                fprintf(stderr, "  b=%d: done_top %d done_D %d chain_next", bb, fl[o_top + bb], fl[o_D + bb]);
+                for (int d = 0; d < F; ++d) fprintf(stderr, " %d", fl[o_cn + SF_DF_FRONT_MAX * bb + d]);
+                fprintf(stderr, " | row_L:");
+                for (int i = 0; i < nt; ++i) fprintf(stderr, " %d", fl[o_L + (long)bb * nt + i]);
+                fprintf(stderr, " | done_row:");
+                for (int i = 0; i < nt; ++i) fprintf(stderr, " %d", fl[o_row + (long)bb * nt + i]);
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "  queue heads:");
+            for (int qx = 0; qx < SF_DF_QUEUES; ++qx) fprintf(stderr, " %d", fl[qx]);
+            fprintf(stderr, " of %d / %d tasks\n", a.ntasks[0], a.ntasks[1]);
+        }
+    }
     if (a.dbg) {
         static long long host[16 * SF_CHIP_WGS + 16 * 64 + 8 * 64];
         (void)hipStreamSynchronize(s);
@@ -3764,6 +3850,20 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
         fprintf(stderr, "dataflow per workgroup: waiting %.2f ms (max %.2f), bodies %.2f ms, busy max %.2f ms, %.0f tasks; by type C %.2f FP %.2f FR %.2f R %.2f RP %.2f RR %.2f ms\n",
                 w / grid / 1e5, wmax / 1e5, bd / grid / 1e5, bmax / 1e5, nn / grid, ty[0] / grid / 1e5, ty[1] / grid / 1e5, ty[2] / grid / 1e5,
                 ty[3] / grid / 1e5, ty[4] / grid / 1e5, ty[5] / grid / 1e5);
+        if (a.trace) {
+            std::vector<long long> tr(4 + 4 * (size_t)a.trace_cap);
+            (void)hipMemcpy(tr.data(), a.trace, sizeof(long long) * tr.size(), hipMemcpyDeviceToHost);
+            (void)hipFree(a.trace);
+            if (FILE* f = fopen(trace_file, "w")) {
+                const long long nrec = std::min<long long>(tr[0], a.trace_cap);
+                fprintf(f, "# n=%d batch=%d nt=%d front=%d grid=%d: type(C FP FR R RP RR) k i b workgroup claimed start end (10 ns ticks)\n", n, batch, nt, F, grid);
+                for (long long r = 0; r < nrec; ++r) {
+                    const long long* e = &tr[4 + 4 * r];
+                    fprintf(f, "%lld %lld %lld %lld %lld %lld %lld %lld\n", e[0] & 255, (e[0] >> 8) & 255, (e[0] >> 16) & 255, (e[0] >> 24) & 65535, e[0] >> 40, e[1], e[2], e[3]);
+                }
+                fclose(f);
+            }
+        }
         fprintf(stderr, "dataflow waiting by type: C %.2f FP %.2f FR %.2f R %.2f RP %.2f RR %.2f ms\n", tw[0] / grid / 1e5, tw[1] / grid / 1e5,
                 tw[2] / grid / 1e5, tw[3] / grid / 1e5, tw[4] / grid / 1e5, tw[5] / grid / 1e5);
     }
