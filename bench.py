@@ -884,7 +884,7 @@ def run(args, in_group, rank, local_rank, world, line):
                 "kernel": "k_chol_panel_w / k_chol_panel / k_potrf_dataflow (fused v_mfma_f64_16x16x4_f64 panel steps of the batched "
                 "Cholesky: long-K update + triangular solves + diagonal-tile update; panel pairs when batch x slabs >= 3400, "
                 "128-column panels for their chain and for medium batches, ONE persistent dataflow launch while batch x "
-                "panels <= 1280)",
+                "panels <= 2048)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,

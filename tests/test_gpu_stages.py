@@ -122,6 +122,45 @@ def test_potrf_logdet_sqmah_random_spd(gpu, chol_sequence, n, batch):
     np.testing.assert_allclose(Lgpu, np.linalg.cholesky(A[0, :, :n]), rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("n,batch,calls", [(1024, 24, 60), (1984, 5, 40), (2048, 16, 25)])
+def test_potrf_dataflow_sequence_is_repeatable(gpu, n, batch, calls):
+    """The dataflow sequence is one persistent launch whose workgroups synchronise through counters in memory: the order
+    in which tasks run differs from call to call, the arithmetic must not (fixed split order of every partial sum), and
+    no wait may time out (an aborted launch flags every matrix with SF_INFO_INTERNAL)."""
+    import torch
+    from starfish_amd import _device as D, _lib
+
+    dev = D.device_of()
+    lda = n + 16
+    rng = np.random.default_rng(7)
+    A = np.zeros((batch, n, lda))
+    for b in range(batch):
+        G = rng.standard_normal((n, 48))
+        A[b, :, :n] = G @ G.T / 48 + np.diag(rng.uniform(1.0, 2.0, n))
+    base = D.to_dev(A, dev)
+    work = torch.empty_like(base)
+    info = D.empty((batch,), dev, torch.int32)
+    ws = D.workspace(gpu.sf_potrf_workspace_bytes(n, batch), dev)
+    s = D.stream_ptr(dev)
+    assert gpu.sf_debug_cholesky_sequence(4) == 0
+    try:
+        first = None
+        for it in range(calls):
+            work.copy_(base)
+            _lib.check(gpu.sf_potrf_batch(D.ptr(work), n, lda, n * lda, batch, D.ptr(info), D.ptr(ws), ws.numel(), s))
+            torch.cuda.synchronize()
+            assert int(info.abs().max()) == 0, f"call {it}: info = {info.cpu().numpy().tolist()}"
+            L = torch.tril(work[:, :, :n])
+            if first is None:
+                first = L.clone()
+                err = (first[0] @ first[0].T - base[0, :, :n]).abs().max().item()
+                assert err < 1e-12
+            else:
+                assert torch.equal(L, first), f"call {it} differs from call 0"
+    finally:
+        gpu.sf_debug_cholesky_sequence(-1)
+
+
 def test_potrf_reports_non_positive_pivot(gpu, chol_sequence):
     import torch
     from starfish_amd import _device as D, _lib

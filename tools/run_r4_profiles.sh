@@ -5,6 +5,8 @@ T=${TAG:-r04_k}
 bash tools/profile_bench.sh ${T}_cfg2 --config cfg2 > gpurun_out/${T}_cfg2.log 2>&1
 bash tools/profile_bench.sh ${T}_cfg2_b16 --config cfg2 --batch 16 > gpurun_out/${T}_cfg2_b16.log 2>&1
 bash tools/profile_bench.sh ${T}_fill --fill-only --steps 3 --warmup 1 > gpurun_out/${T}_fill.log 2>&1
+bash tools/profile_bench.sh ${T}_cfg3 --config cfg3 > gpurun_out/${T}_cfg3.log 2>&1
+bash tools/profile_bench.sh ${T}_cfg5 --config cfg5 > gpurun_out/${T}_cfg5.log 2>&1
 python bench.py > gpurun_out/${T}_default_bench_line.json 2> gpurun_out/${T}_default_bench.err
 python tools/batch_sweep.py > gpurun_out/${T}_batch_sweep_cfg2.json 2>/dev/null
 export SF_LIB_PATH=$GRAFT_REPO_ROOT/starfish_amd/libstarfish_amd_tuning.so
