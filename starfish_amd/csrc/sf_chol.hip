@@ -3169,6 +3169,7 @@ struct sf_df_stage {
     int thr_pt;   // FP(b, k+1, d, .) arrivals the front task of (b, k+1, d) waits for (cumulative over the panels of that parity)
     int thr_rp;   // RP(b, i, k, .) arrivals RR(b, i, k) waits for (cumulative)
     int dep;      // RP of this stage re-uses the partial-sum region of stage `dep` (same parity, split): wait for its reduces
+    int fw;       // front width of this panel (slabs k+1 .. k+F are front slabs) | front slabs of panel k+1 that exist << 8
 };
 template <class S>
 __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy out of the constant address space)
@@ -3179,6 +3180,7 @@ __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy
     r.thr_pt = x.thr_pt;
     r.thr_rp = x.thr_rp;
     r.dep = x.dep;
+    r.fw = x.fw;
     return r;
 }
 // One task queue per XCD: matrix b belongs to queue b % 8 (its slabs share the B operand L[panel rows, :k0] through that
@@ -3186,12 +3188,14 @@ __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy
 // HBM reads); a workgroup serves the queue of the XCD it runs on and, once that is exhausted, the others in turn.  Queues
 // with the same number of matrices share a task table (at most two sizes).
 #define SF_DF_QUEUES 8
-#define SF_DF_MAX_STAGES 64  // (two tables of 24-byte entries in the kernel arguments: < 4 KB)
+#define SF_DF_MAX_STAGES 64  // (two tables of 28-byte entries in the kernel arguments: < 4 KB)
 #define SF_DF_FRONT_MAX 6    // slabs k+1 .. k+front of panel k are front slabs (front <= 6, chosen by the batch size)
 #define SF_DF_QTILES (2 * SF_CHIP_WGS / SF_DF_QUEUES)  // partial-sum tiles per queue and stage parity
 struct sf_df_args {
     sf_panel_args p;  // matrix, right-hand side, generator, frame: the per-task fields are filled in by the kernel
-    int nt, batch, front;
+    int nt, batch, front;  // front: the LARGEST front width (the width of panel k is st[.][k].fw & 255: it grows towards the end)
+    int fstart[SF_DF_FRONT_MAX];        // first panel whose front is d slabs wide (index d - 1): chain_next[.][d - 1] counts from there
+    int thr_base[2][2][SF_DF_FRONT_MAX];  // [table][panel parity][d - 1]: partial-sum arrivals of that parity before distance d existed
     int fp_pos;       // position of the front partial sums inside a stage's segment, in 1/256 of its rest tasks
     int bq[2], ntasks[2];  // table v serves the queues with bq[v] matrices
     int pt_cap;       // largest split of the front partial sums: a (matrix, front slab) owns pt_cap tiles per panel parity in region 2
@@ -3206,6 +3210,7 @@ struct sf_df_args {
     long long trace_cap;
     sf_df_stage st[2][SF_DF_MAX_STAGES];
 };
+static_assert(sizeof(sf_df_args) <= 4096, "kernel arguments of k_potrf_dataflow");
 #define SF_DF_LDS_DOUBLES ((37 * DBS + 128) > (4 * GT * GLD + 2 * GT) ? (37 * DBS + 128) : (4 * GT * GLD + 2 * GT))
 #define SF_DF_LDS_BYTES ((SF_DF_LDS_DOUBLES + 4) * sizeof(double))
 
@@ -3257,8 +3262,8 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                         for (int j = 0; j < Bq; ++j) {
                             const int b1 = qx + SF_DF_QUEUES * j;
                             int* ctr = a.chain_next + SF_DF_FRONT_MAX * b1 + dd - 1;
-                            const int k1 = sf_df_load(ctr);  // d = 1: chain task index (panel k1 - 1); d >= 2: panel
-                            const int kp = dd == 1 ? k1 - 1 : k1;
+                            const int k1 = sf_df_load(ctr);  // d = 1: chain task index (panel k1 - 1); d >= 2: panel - fstart
+                            const int kp = dd == 1 ? k1 - 1 : k1 + a.fstart[dd - 1];
                             if (dd == 1 ? k1 >= nt : kp + dd > nt - 1) continue;
                             bool ready = true;
                             if (kp >= 0) {
@@ -3267,7 +3272,8 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                                     ready = sf_df_load(a.row_L + (size_t)b1 * nt + kp + dd) >= kp;
                                     const int St = a.st[vq][kp - 1].St;
                                     if (ready && St > 0)
-                                        ready = sf_df_load(a.fp_cnt + 2 * SF_DF_FRONT_MAX * b1 + SF_DF_FRONT_MAX * (kp & 1) + dd - 1) >= a.st[vq][kp - 1].thr_pt;
+                                        ready = sf_df_load(a.fp_cnt + 2 * SF_DF_FRONT_MAX * b1 + SF_DF_FRONT_MAX * (kp & 1) + dd - 1) >=
+                                                a.st[vq][kp - 1].thr_pt - a.thr_base[vq][kp & 1][dd - 1];
                                 }
                             }
                             if (!ready) continue;
@@ -3275,7 +3281,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                             if (__hip_atomic_compare_exchange_strong(ctr, &expect, k1 + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                                      __HIP_MEMORY_SCOPE_AGENT)) {
                                 cb = b1;
-                                ck = k1;
+                                ck = dd == 1 ? k1 : kp;
                                 cd = dd;
                                 return true;
                             }
@@ -3300,7 +3306,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                         for (int b1 = 0; b1 < a.batch; ++b1) {
                             live = live || sf_df_load(a.chain_next + SF_DF_FRONT_MAX * b1) < nt;
                             for (int dd = 2; dd <= F; ++dd)
-                                live = live || sf_df_load(a.chain_next + SF_DF_FRONT_MAX * b1 + dd - 1) + dd <= nt - 1;
+                                live = live || sf_df_load(a.chain_next + SF_DF_FRONT_MAX * b1 + dd - 1) + a.fstart[dd - 1] + dd <= nt - 1;
                         }
                         if (!live) {
                             t = -5;
@@ -3356,8 +3362,8 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
             while (kst + 1 < nt - 1 && t >= a.st[v][kst + 1].off) ++kst;
             const sf_df_stage st = sf_df_stage_of(a.st[v][kst]);
             // front slabs of panel kst + 1 that exist, front slabs d >= 2 of this panel, ordinary slabs of this panel
-            const int nF = max(0, min(F, nt - 1 - (kst + 1)));
-            const int nord = max(0, nt - kst - 1 - F);
+            const int Fk = st.fw & 255, nF = st.fw >> 8;
+            const int nord = max(0, nt - kst - 1 - Fk);
             const int n_fp = B * nF * st.St;
             const int n_r1 = B * nord * (st.Sr > 1 ? st.Sr : 1);
             // segment: fp_pos/256 of the rest tasks, the front partial sums of the NEXT panel, the other rest tasks, the reduces.
@@ -3384,14 +3390,14 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 const int tile = u / S;  // ordinary slabs matrix by matrix: tasks side by side on an XCD stream the same B operand
                 sp = u - tile * S;
                 bl = tile / nord;
-                i = k + 1 + F + (tile - bl * nord);
+                i = k + 1 + Fk + (tile - bl * nord);
             } else {
                 u -= n_r1 + n_fp;
                 k = kst;
                 S = st.Sr;
                 type = T_RR;
                 bl = u / nord;
-                i = k + 1 + F + (u - bl * nord);
+                i = k + 1 + Fk + (u - bl * nord);
             }
         }
         bl = __builtin_amdgcn_readfirstlane(bl);  // (the divisions above ran on the VALU)
@@ -3456,7 +3462,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 // (own row: its L blocks left of the tail -- row_L; the slab's diagonal tile, updated by the previous panel's step
                 // for this slab, is waited for inside the body, right before step 4)
                 ok = sf_df_wait(kp >= 1 ? a.row_L + (size_t)b * nt + slab : nullptr, kp, a.done_top + b, kp,
-                                St > 0 ? fcnt + SF_DF_FRONT_MAX * (kp & 1) + d - 1 : nullptr, stp.thr_pt, a.done_D + b, kp + 1, &dready, a.abort_flag,
+                                St > 0 ? fcnt + SF_DF_FRONT_MAX * (kp & 1) + d - 1 : nullptr, stp.thr_pt - a.thr_base[vb][kp & 1][d - 1], a.done_D + b, kp + 1, &dready, a.abort_flag,
                                 tid, s_ints + 1);
                 if (!dready) {
                     q.wflag = a.done_D + b;
@@ -3537,12 +3543,13 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 }
             } else {
                 const sf_df_stage st = sf_df_stage_of(a.st[v][k]);
-                const int nord = nt - k - 1 - F;
+                const int Fk = st.fw & 255;
+                const int nord = nt - k - 1 - Fk;
                 q.ksplit = S;
                 q.kchunk = (nk + S - 1) / S;
                 // (the body indexes the partial sums with the matrix number b: slot of (local matrix, slab) minus b S)
                 q.part = a.part + (size_t)(k & 1) * region +
-                         ((int64_t)qcur * SF_DF_QTILES + ((int64_t)bl * nord + (i - k - 1 - F) - b) * S) * (GT * GT);
+                         ((int64_t)qcur * SF_DF_QTILES + ((int64_t)bl * nord + (i - k - 1 - Fk) - b) * S) * (GT * GT);
                 int* rowflag = a.done_row + (size_t)b * nt + i;
                 int* sdone = a.stage_done + (size_t)qcur * nt;
                 if (type == T_R) {
@@ -3559,7 +3566,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     if (ok) sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
                 } else if (type == T_RP) {
                     ok = sf_df_wait(k >= 1 ? a.done_top + b : nullptr, k, rowflag, k, st.dep >= 0 ? sdone + st.dep : nullptr,
-                                    B * (nt - st.dep - 1 - F), nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
+                                    B * (nt - st.dep - 1 - (st.dep >= 0 ? a.st[v][st.dep].fw & 255 : 0)), nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
                     SF_DF_MARK();
                     if (ok) sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
                 } else {
@@ -3694,8 +3701,23 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     // cost more than ordinary ones (partial sums written and read back).  N = 4096, front 1 / 2 / 3 / 4 / 6: B = 16 8.1 / 8.0 /
     // 7.87 / 7.84 / 7.85 ms, B = 32 13.7 / 13.8 / 13.7 / 13.9 / 14.6, B = 64 25.45 / 25.7 / 26.3 / 26.85 / 28.0
     static const int front_env = SF_TUNE_INT("SF_DF_FRONT", 0);
-    const int F = std::max(1, std::min(SF_DF_FRONT_MAX, front_env > 0 ? front_env : (batch <= 20 ? 3 : 1)));
+    const int F0 = std::max(1, std::min(SF_DF_FRONT_MAX, front_env > 0 ? front_env : (batch <= 20 ? 3 : 1)));
+    // ... and for 21-48 matrices the front widens to three slabs for the last panels: where a stage has fewer tasks than the
+    // chip has workgroup slots (batch x slabs left <= 400) AND its K loops are long (2048 columns or more: the front keeps
+    // long-K tasks out of the chain's way, its partial sums cost a round trip through memory).  Same-box, wide front from
+    // that panel on / never (`tools/knobs_potrf.sh`): N = 4096: B = 24 10.55 / 11.2 ms, 32: 13.42 / 13.65, 40: 16.7 / 16.93,
+    // 48: 19.75 / 19.8, 64: 25.7 / 25.5 (not taken from 49 matrices on); N = 3008, B = 32: 6.2 / 6.25; a wide front over the
+    // short K loops of N = 2048 loses 3-5 %.
+    static const int tail_env = SF_TUNE_INT("SF_DF_TAIL", -1);  // (tuning aid: panels of wide front, 0 = none)
+    static const int tailw_env = SF_TUNE_INT("SF_DF_TAIL_FRONT", 3);
+    const int Ftail = std::max(F0, std::min(SF_DF_FRONT_MAX, tailw_env));
+    int kT = nt;  // first panel of the wide front (nt: none)
+    if (tail_env >= 0) kT = std::max(0, nt - 1 - tail_env);
+    else if (batch > 20 && batch <= 48) kT = std::max(2048 / GT, nt - 400 / batch);
+    auto Fof = [&](int k) { return k >= kT ? Ftail : F0; };
+    const int F = Ftail;  // (the largest width: strides of the front's partial sums and counters)
     a.front = F;
+    for (int d = 1; d <= SF_DF_FRONT_MAX; ++d) a.fstart[d - 1] = d <= F0 ? 0 : kT;
     static const int fp_pos_env = SF_TUNE_INT("SF_DF_FP_POS", -1);
     a.fp_pos = fp_pos_env >= 0 ? fp_pos_env : 256;  // (0 / 64 / 128 / 192 / 256: B = 16 7.75 / 7.7 / 7.6 / 7.7 / 7.55 ms, B = 32 13.8 / 13.9 / 13.75 / 13.7 / 13.65)
     a.nt = nt;
@@ -3731,14 +3753,21 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
             continue;
         }
         int off = 0, thr_pt[2] = {0, 0}, thr_rp = 0, last_split[2] = {-1, -1};
+        bool seen[2][SF_DF_FRONT_MAX] = {};
         for (int k = 0; k + 1 < nt; ++k) {
             sf_df_stage& st = a.st[v][k];
             st.off = off;
             // FP(., k+1, ., .): K slabs [fp / GK, k 8) of panel k+1 (everything left of panel k)
-            const int nF = std::max(0, std::min(F, nt - 1 - (k + 1)));
-            const int nord = std::max(0, nt - k - 1 - F);
+            const int nF = std::max(0, std::min(Fof(k + 1), nt - 1 - (k + 1)));
+            const int nord = std::max(0, nt - k - 1 - Fof(k));
+            st.fw = Fof(k) | (nF << 8);
             const int cnt_pt = nF > 0 ? k * kpb - fp / GK : 0;
             st.St = cnt_pt >= 8 ? sf_df_split(B, cnt_pt, st_cap, pt_tasks) : 0;
+            for (int d = 1; d <= nF; ++d)  // (a distance that appears with the wide front has missed the arrivals counted so far)
+                if (!seen[(k + 1) & 1][d - 1]) {
+                    seen[(k + 1) & 1][d - 1] = true;
+                    a.thr_base[v][(k + 1) & 1][d - 1] = thr_pt[(k + 1) & 1];
+                }
             thr_pt[(k + 1) & 1] += st.St;
             st.thr_pt = thr_pt[(k + 1) & 1];
             const int nk = (k * GT > fp ? k * GT - fp : 0) / GK;
@@ -3755,8 +3784,11 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
         }
         a.ntasks[v] = off;
     }
-    if (a.bq[1] == a.bq[0])
+    if (a.bq[1] == a.bq[0]) {
         for (int k = 0; k + 1 < nt; ++k) a.st[1][k] = a.st[0][k];
+        for (int par = 0; par < 2; ++par)
+            for (int d = 0; d < SF_DF_FRONT_MAX; ++d) a.thr_base[1][par][d] = a.thr_base[0][par][d];
+    }
     // algorithmic flops (as the launch sequences count them): update, solve, diagonal-tile update of every panel
     double flops = 0.0;
     for (int k = 0; k + 1 < nt; ++k) {
@@ -3775,7 +3807,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     if (SF_TUNE_FLAG("SF_DF_VERBOSE")) {
         fprintf(stderr, "dataflow: n=%d nt=%d batch=%d tasks=%lld grid=%d lds=%zu bq=%d/%d St/Sr:", n, nt, batch, total, grid,
                 (size_t)SF_DF_LDS_BYTES, a.bq[0], a.bq[1]);
-        for (int k = 0; k + 1 < nt; ++k) fprintf(stderr, " %d/%d", a.st[0][k].St, a.st[0][k].Sr);
+        for (int k = 0; k + 1 < nt; ++k) fprintf(stderr, " %d/%d%s", a.st[0][k].St, a.st[0][k].Sr, k == kT && Ftail > F0 ? "|" : "");
         fprintf(stderr, "\n");
     }
 #endif

@@ -86,7 +86,7 @@ def test_transform_argument_errors(gpu):
     np.testing.assert_allclose(T.instrumental_broaden(w, f, 0.0), f, atol=1e-14)
 
 
-@pytest.mark.parametrize("n,batch", [(64, 3), (192, 9), (256, 5), (1024, 2), (1088, 2), (1984, 3), (640, 40), (3008, 2), (1152, 17)])
+@pytest.mark.parametrize("n,batch", [(64, 3), (192, 9), (256, 5), (1024, 2), (1088, 2), (1984, 3), (640, 40), (3008, 2), (1152, 17), (2560, 28)])
 def test_potrf_logdet_sqmah_random_spd(gpu, chol_sequence, n, batch):
     import torch
     from starfish_amd import _device as D, _lib
@@ -122,7 +122,7 @@ def test_potrf_logdet_sqmah_random_spd(gpu, chol_sequence, n, batch):
     np.testing.assert_allclose(Lgpu, np.linalg.cholesky(A[0, :, :n]), rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("n,batch,calls", [(1024, 24, 60), (1984, 5, 40), (2048, 16, 25)])
+@pytest.mark.parametrize("n,batch,calls", [(1024, 24, 60), (1984, 5, 40), (2048, 16, 25), (2688, 28, 12)])
 def test_potrf_dataflow_sequence_is_repeatable(gpu, n, batch, calls):
     """The dataflow sequence is one persistent launch whose workgroups synchronise through counters in memory: the order
     in which tasks run differs from call to call, the arithmetic must not (fixed split order of every partial sum), and

@@ -39,12 +39,13 @@ for it in range(calls):
     times.append(dt)
     L = torch.tril(A[:, :, :N])
     if ref is None:
-        ref = L[0].clone()
+        ref = L.clone()  # (matrices of queues of different sizes take different split factors: compare call to call)
+        assert (ref[0] @ ref[0].T - base[:, :N]).abs().max().item() < 1e-11
     if int(info.abs().max()) != 0:
         flagged += 1
-    elif not all(torch.equal(L[b], ref) for b in range(B)):
+    elif not torch.equal(L, ref):
         bad += 1
     if dt > 0.5:
         slow += 1
 times.sort()
-print(f"N={N} B={B}: {calls} calls, median {times[len(times) // 2] * 1e3:.2f} ms, max {times[-1] * 1e3:.1f} ms, slow (> 0.5 s) {slow}, flagged {flagged}, results differing between matrices or calls {bad}")
+print(f"N={N} B={B}: {calls} calls, median {times[len(times) // 2] * 1e3:.2f} ms, max {times[-1] * 1e3:.1f} ms, slow (> 0.5 s) {slow}, flagged {flagged}, results differing from the first call {bad}")
