@@ -187,6 +187,42 @@ def test_cfg2_full_size_n4096_vs_reference(chol_sequence):
     np.testing.assert_allclose(fw["flux"][0], g["n4096_flux"], rtol=0, atol=1e-10)
 
 
+@pytest.mark.parametrize("batch", [32, 45])
+def test_cfg2_strong_split_batches_dataflow_vs_fused_and_oracle(batch):
+    """The batches a strong split of config 2 leaves per GPU run on the dataflow sequence by the library's own choice; from
+    21 to 48 matrices its front widens over the last panels (per-panel front width, counters that start late).  Same walkers
+    through the fused launch sequence: same values to rounding; two of them against the pinned oracle; the reference's own
+    values for the walkers the fixture holds."""
+    from starfish_amd import _lib
+
+    g = load_golden("model_cfg2.npz")
+    o = synth.make_order(N=4096)
+    oo = oracle_order(o)
+    do = device_order(oo)
+    P = synth.walker_ball(o, B=batch, seed=3)
+    nref = min(len(g["n4096_batch_P"]), 4)
+    plist = [synth.vector_to_oracle_params(p) for p in g["n4096_batch_P"][:nref]] + [synth.vector_to_oracle_params(p) for p in P[nref:]]
+    md, rows = pack_rows(do, plist)
+    lib = _lib.require_gpu()
+    auto = do.loglike(md, rows)  # (batch x panels <= 2048: dataflow)
+    assert (auto["info"] == 0).all()
+    assert lib.sf_debug_cholesky_sequence(0) == 0
+    try:
+        fused = do.loglike(md, rows)
+    finally:
+        lib.sf_debug_cholesky_sequence(-1)
+    assert (fused["info"] == 0).all()
+    np.testing.assert_allclose(auto["lnl"], fused["lnl"], rtol=1e-12)
+    np.testing.assert_allclose(auto["logdet"], fused["logdet"], rtol=1e-13)
+    np.testing.assert_allclose(auto["sqmah"], fused["sqmah"], rtol=1e-10)
+    for b in range(nref):
+        assert close_lnl(auto["lnl"][b], g["n4096_batch_lnl"][b])
+    for b in (nref, batch - 1):
+        assert close_lnl(auto["lnl"][b], O.log_likelihood(oo, plist[b]))
+    again = do.loglike(md, rows)
+    np.testing.assert_array_equal(again["lnl"], auto["lnl"])
+
+
 def test_cfg5_long_order_n16384_vs_reference(chol_sequence):
     """BASELINE config 5 (N = 16384, N_f = 32768: FFT through the global-memory path) against the value
     produced by the real reference."""
