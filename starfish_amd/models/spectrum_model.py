@@ -470,7 +470,7 @@ class SpectrumModel:
         priors = {} if priors is None else priors
         for key, val in priors.items():
             if key not in self.params and not key.startswith("cheb"):
-                raise ValueError(f"Invalid priors. {key} not a vlid key.")
+                raise ValueError(f"Invalid priors: {key!r} is not a parameter of this model")
             if not callable(getattr(val, "logpdf", None)):
                 raise ValueError(f"Invalid priors. {key} does not have a `logpdf` method")
             log_prob = val.logpdf(self[key])
