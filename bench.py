@@ -427,6 +427,17 @@ def fill_leg(w, steps=5, warmup=2):
     }
 
 
+def device_note():
+    """Name and compute units of rank 0's GPU (boxes of the pool differ by a few per cent at the small batches)."""
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        return {"name": pr.name, "compute_units": int(pr.multi_processor_count), "memory_GB": round(pr.total_memory / 2**30, 1)}
+    except Exception as e:  # (never fatal: a note)
+        return {"error": str(e)[:80]}
+
+
 def pmc_lookup(tag, kernel_key, total=False):
     """(hbm bytes per launch, source file, collected-on-this-code?) of the latest profiles/r0?_*<tag>*_pmc_summary.json;
     total: summed over every kernel whose name starts with the key (one launch of each per step)."""
@@ -876,6 +887,7 @@ def run(args, in_group, rank, local_rank, world, line):
                 "units_per_gpu": w.n_local,
                 "parallelism": f"(order x walker) units sharded x{world}, one process per GPU, no data-path collective"
                 + (f" (process group: {pg_note}, barrier + timing max only)" if use_dist else ""),
+                "device": device_note(),
             },
             "process_group": pg_note,
             "whole_path_tflops": t["value"] * w.flops_eval / 1e12,
