@@ -57,8 +57,13 @@ extern "C" {
 #define SF_INFO_BAD_VSINI (-2)   /* vsini <= 0: transforms.py:121-122 */
 #define SF_INFO_BAD_WEIGHT_COV (-3) /* Sigma_w not positive definite: spectrum_model.py:334 */
 #define SF_INFO_BANDWIDTH (-4)   /* banded solver only: covariance support wider than the given half-width */
-#define SF_INFO_INTERNAL (-5)    /* banded solver only: a wave-synchronisation wait inside the sweep timed out;
-                                    cannot happen by construction (the bound keeps a logic error from hanging the GPU) */
+#define SF_INFO_INTERNAL (-5)    /* a bounded wait between workgroups / waves of ONE launch timed out: the banded sweep's wave
+                                    synchronisation, or a dependency counter of the persistent-kernel Cholesky (the default
+                                    sequence of small batches) -- there EVERY matrix of the call carries the code and no
+                                    result of the call is valid.  Not expected to happen (the schedules are live by construction;
+                                    the bound keeps a logic or hardware error from hanging the GPU).  Callers recover by
+                                    sf_persistent_potrf(0) and re-running the batch (starfish_amd/_device.py does, with a
+                                    warning); it is never to be treated as a rejected walker */
 
 #define SF_INFO_NAN (-6)         /* the likelihood came out NaN although every stage reported success: lnl = -inf, but
                                     distinguishable from a legitimately rejected walker */
@@ -324,6 +329,11 @@ int sf_profile_read(double* ms_by_stage, double* gemm_flops, long* gemm_launches
  * objective evaluation, followed by sf_potrf_batch + sf_logdet_sqmah_batch with the right-hand side w_hat. */
 int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, const double* d_hyper, const double* d_iphiphi,
                           double* d_A, int npad, int lda, void* stream);
+
+/* Process-global switch of the persistent-kernel ("dataflow") Cholesky sequence: enable = 0 makes every later factorisation
+ * take a launch sequence (kernels without waits inside), 1 restores the default choice, < 0 only queries.  Returns the
+ * previous setting.  The recovery path after SF_INFO_INTERNAL. */
+int sf_persistent_potrf(int enable);
 
 /* Tuning / test aid (process-global): the batched Cholesky has three launch sequences -- the fused panel kernel
  * (128-column panels, two workgroups per CU; medium batches), the unfused one (256-column panels, separate panel-solve and

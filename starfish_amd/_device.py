@@ -14,11 +14,30 @@ INFO_MESSAGES = {
     -2: "vsini must be positive",
     -3: "emulator weight covariance is not positive definite",
     -4: "covariance support wider than the band half-width given to the banded solver",
-    -5: "internal error: the banded sweep's wave synchronisation timed out (please report)",
+    -5: "internal error: a bounded wait inside a persistent kernel timed out (banded sweep or dataflow Cholesky; "
+        "no result of that call is valid -- please report)",
     -6: "the log-likelihood evaluated to NaN (non-finite input or intermediate)",
 }
 INFO_BANDWIDTH = -4
+INFO_INTERNAL = -5
 C_KMS = 2.99792458e5
+
+
+def recover_from_internal(lib, where, count):
+    """A dense call came back with SF_INFO_INTERNAL: a wait inside the persistent-kernel Cholesky timed out and the whole
+    batch is invalid (include/starfish_amd.h).  The reference would never turn that into a rejected proposal
+    (spectrum_model.py:400 raises out of cho_factor), so: say so loudly, switch the process to the launch sequences
+    (no waits inside kernels) and let the caller re-run the batch."""
+    import warnings
+
+    warnings.warn(
+        f"{where}: internal status -5 for {int(count)} unit(s) -- the persistent-kernel Cholesky aborted a launch; "
+        "it is now disabled for this process (sf_persistent_potrf(0)) and the batch is re-run on the launch sequence. "
+        "Please report this.",
+        RuntimeWarning,
+        stacklevel=3,
+    )
+    lib.sf_persistent_potrf(0)
 
 
 def _torch():
@@ -194,7 +213,13 @@ class MultiPlan:
                 _lib.check(rc, "sf_loglike_multi_batch")
 
     def collect(self):
-        return collect_multi(self.quad, self.info, self.sizes)
+        out = collect_multi(self.quad, self.info, self.sizes)
+        bad = sum(int((o["info"] == INFO_INTERNAL).sum()) for o in out)
+        if bad:  # an aborted persistent launch invalidates the whole call: re-run on the launch sequence, once
+            recover_from_internal(self.lib, "sf_loglike_multi_batch", bad)
+            self.enqueue()
+            out = collect_multi(self.quad, self.info, self.sizes)
+        return out
 
 
 def loglike_multi(orders, md, rows_list, max_units=None, sync=True):
@@ -365,7 +390,7 @@ class DeviceOrder:
         _lib.check(rc, "sf_loglike_banded_batch")
 
     # ------------------------------------------------------------------ batched calls
-    def loglike(self, md, params, want_resid=False, max_chunk=None, solver="dense"):
+    def loglike(self, md, params, want_resid=False, max_chunk=None, solver="dense", _retry=True):
         """params: (B, stride) float64 (numpy or cuda tensor) in the C-ABI row layout.
         Returns dict of numpy arrays: lnl, logdet, sqmah, log_scale, info (+ resid).
 
@@ -398,6 +423,11 @@ class DeviceOrder:
                 _lib.check(rc, "sf_loglike_batch")
             host = quad.cpu().numpy()
             out = dict(lnl=host[0], logdet=host[1], sqmah=host[2], log_scale=host[3], info=info.cpu().numpy())
+            internal = out["info"] == INFO_INTERNAL
+            if internal.any() and _retry:
+                # never a silent -inf: warn, switch the persistent kernel off, evaluate the batch again
+                recover_from_internal(self.lib, "sf_loglike_batch", internal.sum())
+                return self.loglike(md, P, want_resid=want_resid, max_chunk=max_chunk, solver="dense", _retry=False)
             if want_resid:
                 out["resid"] = resid.cpu().numpy()
             return out
@@ -460,15 +490,16 @@ class DeviceOrder:
             out["info"][idx] = info.cpu().numpy()
             if want_resid:
                 out["resid"][idx] = resid.cpu().numpy()
-        rest = np.array([], dtype=int)
-        if solver == "auto":
-            # too wide for the banded kernels -> dense; an internal wait timeout (-5, cannot happen by construction) is
-            # recomputed by the dense solver too instead of silently turning into a rejected walker
-            internal = out["info"] == -5
-            if internal.any():
-                import warnings
+        # an internal wait timeout of the sweep (-5, not expected: the bound keeps a logic error from hanging the GPU) is
+        # recomputed by the dense solver -- under "banded" too -- instead of silently turning into a rejected walker
+        internal = out["info"] == INFO_INTERNAL
+        if internal.any():
+            import warnings
 
-                warnings.warn(f"banded solver: internal status -5 for {int(internal.sum())} walker(s); recomputed densely")
+            warnings.warn(f"banded solver: internal status -5 for {int(internal.sum())} walker(s); recomputed densely",
+                          RuntimeWarning)
+        rest = np.nonzero(internal)[0]
+        if solver == "auto":  # too wide for the banded kernels -> dense
             rest = np.nonzero(~fits | (out["info"] == INFO_BANDWIDTH) | internal)[0]
         if rest.size:
             dense = self.loglike(md, rows[rest], want_resid=want_resid, max_chunk=pend["max_chunk"], solver="dense")

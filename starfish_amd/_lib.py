@@ -151,6 +151,7 @@ SIGNATURES = {
     "sf_debug_clock_probe": (C.c_int, [_VP, C.c_longlong, _VP]),
     "sf_debug_stream_write": (C.c_int, [_VP, C.c_size_t, C.c_double, _VP]),
     "sf_debug_cholesky_sequence": (C.c_int, [C.c_int]),
+    "sf_persistent_potrf": (C.c_int, [C.c_int]),
     "sf_profile_enable": (C.c_int, [C.c_int]),
     "sf_profile_read": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
 }

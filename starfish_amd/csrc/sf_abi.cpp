@@ -1696,6 +1696,10 @@ extern "C" int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, 
     return sf_launch_v11_build(d_grid, M, P, m, d_hyper, d_iphiphi, d_A, npad, lda, (hipStream_t)stream);
 }
 
+// Recovery switch of the callers (process-global): after a batch came back SF_INFO_INTERNAL the host layer turns the
+// persistent-kernel sequence off and re-runs the batch on a launch sequence (starfish_amd/_device.py).
+extern "C" int sf_persistent_potrf(int enable) { return sf_set_persistent_potrf(enable); }
+
 // Tuning / test aid: pin the launch sequence of the batched Cholesky (process-global).
 extern "C" int sf_debug_cholesky_sequence(int mode) { return sf_set_cholesky_sequence(mode); }
 

@@ -1253,9 +1253,22 @@ __device__ __forceinline__ void sf_df_report(int* abort_flag, const int* f, int 
 // is then covered by this acquire and needs no wait of its own later.  Returns false when the launch is being aborted.
 // (s_okp: one int of LDS -- the kernels keep their LDS image at offset 0 of the workgroup's allocation, so no static __shared__
 // variable may exist beside the dynamic buffer: with sm at offset 16 the direct-to-LDS operand loads lose their alignment)
-__device__ __forceinline__ bool sf_df_wait(const int* f1, int t1, const int* f2, int t2, const int* f3, int t3,
-                                           const int* probe, int tprobe, bool* probe_ok, int* abort_flag, const int tid,
-                                           int* s_okp) {
+// `rescue` (queued tasks' waits BEFORE their bodies only): a callable that looks for a ready chain / front task nobody has
+// claimed and claims it; after SF_DF_RESCUE_TICKS inside one wait the polling lane calls it every ~50 us.  When it returns
+// true the wait ends with SF_DF_DEFERRED: the workgroup sets its task aside, runs the chain task it has just claimed and
+// comes back (k_potrf_dataflow).  This is what makes the schedule live BY CONSTRUCTION: chain and front tasks are claimed by
+// whoever finds them ready at the dispenser, and a claim can be missed (see there); a workgroup that waits before a body
+// holds nothing but its task number, and in-body waits only ever depend on tasks that are already running.  The normal path
+// never gets here: waits that long mean the chip is starved of chain progress anyway.
+#define SF_DF_RESCUE_TICKS 50000LL  // 500 us of the 100 MHz wall clock
+#define SF_DF_DEFERRED 4
+struct sf_df_no_rescue {
+    __device__ __forceinline__ bool operator()() const { return false; }
+};
+template <class RESCUE>
+__device__ __forceinline__ int sf_df_wait_r(const int* f1, int t1, const int* f2, int t2, const int* f3, int t3,
+                                            const int* probe, int tprobe, bool* probe_ok, int* abort_flag, const int tid,
+                                            int* s_okp, RESCUE&& rescue, const bool can_rescue) {
     if (tid == 0) {
         int ok = 1;
         // (short-circuit on purpose: a poller asks for the first counter that is missing only -- polls of all three, every
@@ -1274,10 +1287,15 @@ __device__ __forceinline__ bool sf_df_wait(const int* f1, int t1, const int* f2,
                         ok = 0;
                         break;
                     }
-                    if (wall_clock64() - t0 > SF_DF_TIMEOUT_TICKS) {
+                    const long long waited = wall_clock64() - t0;
+                    if (waited > SF_DF_TIMEOUT_TICKS) {
                         const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
                         sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3));
                         ok = 0;
+                        break;
+                    }
+                    if (can_rescue && waited > SF_DF_RESCUE_TICKS && rescue()) {
+                        ok = SF_DF_DEFERRED;
                         break;
                     }
                 }
@@ -1291,7 +1309,12 @@ __device__ __forceinline__ bool sf_df_wait(const int* f1, int t1, const int* f2,
     const int ok = __builtin_amdgcn_readfirstlane(*s_okp);
     __syncthreads();  // (s_ok is rewritten by the next wait)
     if (probe_ok) *probe_ok = (ok & 2) != 0;
-    return (ok & 1) != 0;
+    return ok & (1 | SF_DF_DEFERRED);
+}
+__device__ __forceinline__ bool sf_df_wait(const int* f1, int t1, const int* f2, int t2, const int* f3, int t3,
+                                           const int* probe, int tprobe, bool* probe_ok, int* abort_flag, const int tid,
+                                           int* s_okp) {
+    return sf_df_wait_r(f1, t1, f2, t2, f3, t3, probe, tprobe, probe_ok, abort_flag, tid, s_okp, sf_df_no_rescue(), false) == 1;
 }
 __device__ __forceinline__ bool sf_df_wait(const int* flag, int target, int* abort_flag, const int tid, int* s_okp) {
     return sf_df_wait(flag, target, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, abort_flag, tid, s_okp);
@@ -3190,6 +3213,7 @@ __host__ __device__ __forceinline__ sf_df_stage sf_df_stage_of(S& x) {  // (copy
 #define SF_DF_QUEUES 8
 #define SF_DF_MAX_STAGES 64  // (two tables of 28-byte entries in the kernel arguments: < 4 KB)
 #define SF_DF_FRONT_MAX 6    // slabs k+1 .. k+front of panel k are front slabs (front <= 6, chosen by the batch size)
+#define SF_DF_FRONT_WIDEST 3 // ... and the widest front a release build chooses: the stride of the front's partial sums and counters
 #define SF_DF_QTILES (2 * SF_CHIP_WGS / SF_DF_QUEUES)  // partial-sum tiles per queue and stage parity
 struct sf_df_args {
     sf_panel_args p;  // matrix, right-hand side, generator, frame: the per-task fields are filled in by the kernel
@@ -3206,6 +3230,7 @@ struct sf_df_args {
     double* part;     // three regions of sf_split_region_tiles() tiles: rest partial sums by stage parity, front partial sums
     int* info;
     long long* dbg;   // tuning builds: per workgroup {ticks waiting, ticks in task bodies, tasks, ticks by type} (100 MHz)
+    int miss_claims;  // tuning builds (SF_DF_MISS_CLAIMS): the dispenser leaves chain / front tasks to the waits' rescue while its queues hold tasks
     long long* trace; // tuning builds (SF_DF_TRACE_FILE): [0] = records written, then {type | k << 8 | i << 16 | b << 24 | workgroup << 40, claimed, body start, end}
     long long trace_cap;
     sf_df_stage st[2][SF_DF_MAX_STAGES];
@@ -3213,6 +3238,50 @@ struct sf_df_args {
 static_assert(sizeof(sf_df_args) <= 4096, "kernel arguments of k_potrf_dataflow");
 #define SF_DF_LDS_DOUBLES ((37 * DBS + 128) > (4 * GT * GLD + 2 * GT) ? (37 * DBS + 128) : (4 * GT * GLD + 2 * GT))
 #define SF_DF_LDS_BYTES ((SF_DF_LDS_DOUBLES + 4) * sizeof(double))
+
+typedef const __attribute__((address_space(4))) sf_df_args sf_df_kargs;
+#ifdef SF_TUNING
+#define SF_DF_MISS_CLAIMS(x) (a.miss_claims && (x))
+#else
+#define SF_DF_MISS_CLAIMS(x) (false)
+#endif
+// A ready chain (d = 1) / front (d >= 2) task among the matrices of queue qx that nobody has claimed?  Claims it by
+// compare-and-swap on the matrix's counter: cb = matrix, ck = chain task index (d = 1) or panel (d >= 2), cd = d.  One lane.
+__device__ __forceinline__ bool sf_df_try_chain(sf_df_kargs& a, const int qx, int& cb, int& ck, int& cd) {
+    const int nt = a.nt, F = a.front;
+    const int Bq = (a.batch - qx + SF_DF_QUEUES - 1) / SF_DF_QUEUES;
+    const int vq = Bq == a.bq[0] ? 0 : 1;
+    for (int dd = 1; dd <= F; ++dd) {  // (the chain itself first)
+        for (int j = 0; j < Bq; ++j) {
+            const int b1 = qx + SF_DF_QUEUES * j;
+            int* ctr = a.chain_next + SF_DF_FRONT_MAX * b1 + dd - 1;
+            const int k1 = sf_df_load(ctr);  // d = 1: chain task index (panel k1 - 1); d >= 2: panel - fstart
+            const int kp = dd == 1 ? k1 - 1 : k1 + a.fstart[dd - 1];
+            if (dd == 1 ? k1 >= nt : kp + dd > nt - 1) continue;
+            bool ready = true;
+            if (kp >= 0) {
+                ready = sf_df_load(a.done_top + b1) >= kp;
+                if (ready && kp >= 1) {
+                    ready = sf_df_load(a.row_L + (size_t)b1 * nt + kp + dd) >= kp;
+                    const int St = a.st[vq][kp - 1].St;
+                    if (ready && St > 0)
+                        ready = sf_df_load(a.fp_cnt + 2 * SF_DF_FRONT_MAX * b1 + SF_DF_FRONT_MAX * (kp & 1) + dd - 1) >=
+                                a.st[vq][kp - 1].thr_pt - a.thr_base[vq][kp & 1][dd - 1];
+                }
+            }
+            if (!ready) continue;
+            int expect = k1;
+            if (__hip_atomic_compare_exchange_strong(ctr, &expect, k1 + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                cb = b1;
+                ck = dd == 1 ? k1 : kp;
+                cd = dd;
+                return true;
+            }
+        }
+    }
+    return false;
+}
 
 template <bool RHS>
 __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in) {
@@ -3225,7 +3294,6 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
     // the thread index is recomputed per task (the index is laundered through an empty asm): otherwise hipcc hoists the
     // lane-dependent invariants of all the inlined task bodies out of the loop and spills them (600 bytes of scratch per
     // lane, scratch loads inside the MFMA loops).
-    typedef const __attribute__((address_space(4))) sf_df_args sf_df_kargs;
     sf_df_kargs* ap = (sf_df_kargs*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)a_in;
     // (workgroup b of a launch runs on XCD b % 8 -- observed, not promised; placement is a speed matter only here: any
@@ -3234,6 +3302,9 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
     int visited = 0;
     int kst = 0;  // stage hint: a workgroup draws the tasks of a queue in increasing order
     if (threadIdx.x == 0) s_ints[5] = 0;  // (idle spell of the end-of-launch phase, see the dispenser)
+    // A queued task whose wait was interrupted to run a chain / front task nobody had claimed (sf_df_wait_r): resume = 1 the
+    // claimed chain task is in s_ints[0..4] already; pend_t >= 0: that queued task is taken up again instead of a new one.
+    int pend_t = -1, resume = 0;
     for (;;) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -3250,45 +3321,19 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
         // by then, the workgroups of the other queues do at the end of the launch, when each looks at every chain.  Measured
         // and not taken: waiting for this workgroup's counter stores to be acknowledged before the scan (2 % of a launch),
         // one lane per candidate instead of one lane walking the matrices (claims cost 20 instead of 28 us, launches of 8-32
-        // matrices ran 2-5 % slower), waits that give up after 20 us to serve the chains and come back (3-14 % slower).)
-        if (tid == 0) {
+        // matrices ran 2-5 % slower), waits that give up after 20 us to serve the chains and come back (3-14 % slower).
+        // Since round 5 the window is closed where it matters: a queued task's wait that has lasted 500 us looks at the chains
+        // itself, sf_df_wait_r.)
+        if (resume) {  // s_ints[0..4] = the chain task claimed inside the interrupted wait
+            resume = 0;
+        } else if (pend_t >= 0) {  // back to the task that was set aside
+            if (tid == 0) s_ints[0] = pend_t;
+            pend_t = -1;
+        } else if (tid == 0) {
             int t = -1, cb = 0, ck = 0, cd = 1;
             if (sf_df_load(a.abort_flag) == 0) {
                 t = -2;
-                auto try_chain = [&](int qx) {  // a ready chain / front task among the matrices of queue qx?
-                    const int Bq = (a.batch - qx + SF_DF_QUEUES - 1) / SF_DF_QUEUES;
-                    const int vq = Bq == a.bq[0] ? 0 : 1;
-                    for (int dd = 1; dd <= F; ++dd) {  // (the chain itself first)
-                        for (int j = 0; j < Bq; ++j) {
-                            const int b1 = qx + SF_DF_QUEUES * j;
-                            int* ctr = a.chain_next + SF_DF_FRONT_MAX * b1 + dd - 1;
-                            const int k1 = sf_df_load(ctr);  // d = 1: chain task index (panel k1 - 1); d >= 2: panel - fstart
-                            const int kp = dd == 1 ? k1 - 1 : k1 + a.fstart[dd - 1];
-                            if (dd == 1 ? k1 >= nt : kp + dd > nt - 1) continue;
-                            bool ready = true;
-                            if (kp >= 0) {
-                                ready = sf_df_load(a.done_top + b1) >= kp;
-                                if (ready && kp >= 1) {
-                                    ready = sf_df_load(a.row_L + (size_t)b1 * nt + kp + dd) >= kp;
-                                    const int St = a.st[vq][kp - 1].St;
-                                    if (ready && St > 0)
-                                        ready = sf_df_load(a.fp_cnt + 2 * SF_DF_FRONT_MAX * b1 + SF_DF_FRONT_MAX * (kp & 1) + dd - 1) >=
-                                                a.st[vq][kp - 1].thr_pt - a.thr_base[vq][kp & 1][dd - 1];
-                                }
-                            }
-                            if (!ready) continue;
-                            int expect = k1;
-                            if (__hip_atomic_compare_exchange_strong(ctr, &expect, k1 + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_AGENT)) {
-                                cb = b1;
-                                ck = dd == 1 ? k1 : kp;
-                                cd = dd;
-                                return true;
-                            }
-                        }
-                    }
-                    return false;
-                };
+                auto try_chain = [&](int qx) { return SF_DF_MISS_CLAIMS(visited < SF_DF_QUEUES) ? false : sf_df_try_chain(a, qx, cb, ck, cd); };
                 if (try_chain(qcur)) {
                     t = -3;
                 } else if (visited < SF_DF_QUEUES) {
@@ -3515,77 +3560,108 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
             }
             if (type == T_C) __builtin_amdgcn_s_setprio(0);
         } else {
+            // ---- queued tasks: ONE wait site for the four types (it carries the chain rescue, see sf_df_wait_r)
             const int k0 = k * GT;
             const int nk = (k0 > fp ? k0 - fp : 0) / GK;
             q.k0 = k0;
             q.pw = min(GT, n - k0);
             q.Wt = Wof(k);
             q.row0 = i * GT;
+            const sf_df_stage st = sf_df_stage_of(a.st[v][k]);
+            const int Fk = st.fw & 255;
+            const int nord = nt - k - 1 - Fk;
+            int* rowflag = a.done_row + (size_t)b * nt + i;
+            int* sdone = a.stage_done + (size_t)qcur * nt;
+            const int *f1, *f2, *f3 = nullptr, *probe = nullptr;
+            int t1, t2, t3 = 0;
+            q.ksplit = S;
             if (type == T_FP) {
                 // slab k+d, panel k, K slabs [fp / GK, (k - 1) 8): rows k and k+d through panel k-2; the slots' previous user (the
                 // front task of (b, k-2, d)) must have read them: the chain's second half for d = 1, the row counter otherwise
                 const int cnt = (k - 1) * (GT / GK) - fp / GK;
-                q.ksplit = S;
                 q.kchunk = (cnt + S - 1) / S;
                 q.kstop = (k - 1) * (GT / GK);
                 q.part = fpart(k, d, S);
-                ok = sf_df_wait(a.done_row + (size_t)b * nt + k, k - 1, a.done_row + (size_t)b * nt + i, k - 1,
-                                d == 1 ? a.done_D + b : a.done_row + (size_t)b * nt + i - 2, d == 1 ? k : k - 1, nullptr, 0, nullptr,
-                                a.abort_flag, tid, s_ints + 1);
-                SF_DF_MARK();
-                if (ok) {
-                    sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
-                    __syncthreads();
-                    if (tid == 0) {
-                        sf_df_release();
-                        sf_df_add(fcnt + SF_DF_FRONT_MAX * (k & 1) + d - 1, 1);
-                    }
-                }
+                f1 = a.done_row + (size_t)b * nt + k;
+                t1 = k - 1;
+                f2 = rowflag;
+                t2 = k - 1;
+                f3 = d == 1 ? a.done_D + b : a.done_row + (size_t)b * nt + i - 2;
+                t3 = d == 1 ? k : k - 1;
             } else {
-                const sf_df_stage st = sf_df_stage_of(a.st[v][k]);
-                const int Fk = st.fw & 255;
-                const int nord = nt - k - 1 - Fk;
-                q.ksplit = S;
                 q.kchunk = (nk + S - 1) / S;
                 // (the body indexes the partial sums with the matrix number b: slot of (local matrix, slab) minus b S)
                 q.part = a.part + (size_t)(k & 1) * region +
                          ((int64_t)qcur * SF_DF_QTILES + ((int64_t)bl * nord + (i - k - 1 - Fk) - b) * S) * (GT * GT);
-                int* rowflag = a.done_row + (size_t)b * nt + i;
-                int* sdone = a.stage_done + (size_t)qcur * nt;
-                if (type == T_R) {
+                if (type == T_RR) {
+                    f1 = a.rp_cnt + (size_t)b * nt + i;
+                    t1 = st.thr_rp;
+                    f2 = a.done_D + b;
+                    t2 = k + 1;
+                } else {
                     // K loop: row k through panel k-1 (the chain task's first half), the slab's own row through panel k-1; only
-                    // the solve needs the diagonal tile -- if that is there already, this acquire covers it
-                    bool dready = false;
-                    ok = sf_df_wait(k >= 1 ? a.done_top + b : nullptr, k, rowflag, k, nullptr, 0, a.done_D + b, k + 1, &dready,
-                                    a.abort_flag, tid, s_ints + 1);
+                    // the solve needs the diagonal tile -- if that is there already, this acquire covers it (T_R: probe)
+                    f1 = k >= 1 ? a.done_top + b : nullptr;
+                    t1 = k;
+                    f2 = rowflag;
+                    t2 = k;
+                    if (type == T_R) {
+                        probe = a.done_D + b;
+                    } else if (st.dep >= 0) {  // T_RP re-uses the partial-sum slots of stage dep: its reduces must have read them
+                        f3 = sdone + st.dep;
+                        t3 = B * (nt - st.dep - 1 - (a.st[v][st.dep].fw & 255));
+                    }
+                }
+            }
+            bool dready = false;
+            const int wr = sf_df_wait_r(f1, t1, f2, t2, f3, t3, probe, k + 1, &dready, a.abort_flag, tid, s_ints + 1,
+                                        [&]() {  // (one lane) a ready chain / front task that nobody has claimed, on any queue
+                                            int cb = 0, ck = 0, cd = 1;
+                                            for (int x = 0; x < SF_DF_QUEUES; ++x)
+                                                if (sf_df_try_chain(a, (qcur + x) & (SF_DF_QUEUES - 1), cb, ck, cd)) {
+                                                    s_ints[0] = -3;
+                                                    s_ints[2] = cb;
+                                                    s_ints[3] = ck;
+                                                    s_ints[4] = cd;
+                                                    return true;
+                                                }
+                                            return false;
+                                        },
+                                        true);
+            if (wr == SF_DF_DEFERRED) {  // a chain task first (claimed in the wait), then this task again
+                pend_t = t;
+                resume = 1;
+                continue;
+            }
+            ok = wr == 1;
+            SF_DF_MARK();
+            if (ok) {
+                if (type == T_FP) {
+                    sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
+                } else if (type == T_R) {
                     if (!dready) {
                         q.wflag = a.done_D + b;
                         q.wval = k + 1;
                     }
-                    SF_DF_MARK();
-                    if (ok) sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
+                    sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
                 } else if (type == T_RP) {
-                    ok = sf_df_wait(k >= 1 ? a.done_top + b : nullptr, k, rowflag, k, st.dep >= 0 ? sdone + st.dep : nullptr,
-                                    B * (nt - st.dep - 1 - (st.dep >= 0 ? a.st[v][st.dep].fw & 255 : 0)), nullptr, 0, nullptr, a.abort_flag, tid, s_ints + 1);
-                    SF_DF_MARK();
-                    if (ok) sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
+                    sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
                 } else {
-                    ok = sf_df_wait(a.rp_cnt + (size_t)b * nt + i, st.thr_rp, a.done_D + b, k + 1, nullptr, 0, nullptr, 0, nullptr,
-                                    a.abort_flag, tid, s_ints + 1);
-                    SF_DF_MARK();
-                    if (ok) sf_panel_body<RHS, 2>(g, q, b, sm, red, tid);
+                    sf_panel_body<RHS, 2>(g, q, b, sm, red, tid);
                 }
-                // (a workgroup that left the body on a timed-out wait finds the abort flag at the dispenser)
-                __syncthreads();
-                if (ok && tid == 0) {
-                    sf_df_release();
-                    if (type == T_RP) {
-                        sf_df_add(a.rp_cnt + (size_t)b * nt + i, 1);
-                    } else {
-                        sf_df_set(a.row_L + (size_t)b * nt + i, k + 1);
-                        sf_df_set(rowflag, k + 1);
-                        if (type == T_RR) sf_df_add(sdone + k, 1);
-                    }
+            }
+            // (a workgroup that left the body on a timed-out wait finds the abort flag at the dispenser)
+            __syncthreads();
+            if (ok && tid == 0) {
+                sf_df_release();
+                if (type == T_FP) {
+                    sf_df_add(fcnt + SF_DF_FRONT_MAX * (k & 1) + d - 1, 1);
+                } else if (type == T_RP) {
+                    sf_df_add(a.rp_cnt + (size_t)b * nt + i, 1);
+                } else {
+                    sf_df_set(a.row_L + (size_t)b * nt + i, k + 1);
+                    sf_df_set(rowflag, k + 1);
+                    if (type == T_RR) sf_df_add(sdone + k, 1);
                 }
             }
         }
@@ -3656,7 +3732,10 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     int* flags = (int*)Wt2;
     const size_t ndbg = 2 * (16 * SF_CHIP_WGS + 16 * 64 + 8 * 64);
     const size_t nflags = 64 + (size_t)batch * (3 * nt + 2 + 3 * SF_DF_FRONT_MAX) + (size_t)SF_DF_QUEUES * nt + 8 + ndbg;
-    if (nt - 1 > SF_DF_MAX_STAGES || nflags * sizeof(int) > 2 * (size_t)batch * sW * sizeof(double)) {
+    // (region 2 of `part` holds 2 x front x batch x pt_cap tiles with pt_cap >= 1: batches beyond what it holds at the widest
+    // front are refused here -- the automatic choice stops at 128 matrices, a forced sequence 4 falls back in sf_launch_potrf)
+    if (nt - 1 > SF_DF_MAX_STAGES || nflags * sizeof(int) > 2 * (size_t)batch * sW * sizeof(double) ||
+        2 * (size_t)SF_DF_FRONT_WIDEST * batch > sf_split_region_tiles()) {
         sf_set_error("potrf: dataflow sequence: %d panels / %d matrices do not fit its tables", nt, batch);
         return SF_EINVAL;
     }
@@ -3673,6 +3752,12 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.stage_done = a.rp_cnt + (size_t)batch * nt;  // [SF_DF_QUEUES][nt]
     SF_HIP(hipMemsetAsync(flags, 0, nflags * sizeof(int), s));
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
+#ifdef SF_TUNING
+    // test aids: a launch that finds its abort flag raised (every matrix comes back SF_INFO_INTERNAL: the callers' recovery
+    // path); a dispenser that leaves every chain / front task to the rescue of the waits (sf_df_wait_r)
+    if (SF_TUNE_FLAG("SF_DF_FORCE_ABORT")) SF_HIP(hipMemsetAsync(a.abort_flag, 1, 1, s));
+    a.miss_claims = SF_TUNE_INT("SF_DF_MISS_CLAIMS", 0);
+#endif
 
     sf_panel_args& g = a.p;
     g.C = A;
@@ -3709,13 +3794,17 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     // 48: 19.75 / 19.8, 64: 25.7 / 25.5 (not taken from 49 matrices on); N = 3008, B = 32: 6.2 / 6.25; a wide front over the
     // short K loops of N = 2048 loses 3-5 %.
     static const int tail_env = SF_TUNE_INT("SF_DF_TAIL", -1);  // (tuning aid: panels of wide front, 0 = none)
-    static const int tailw_env = SF_TUNE_INT("SF_DF_TAIL_FRONT", 3);
+    static const int tailw_env = SF_TUNE_INT("SF_DF_TAIL_FRONT", SF_DF_FRONT_WIDEST);
     const int Ftail = std::max(F0, std::min(SF_DF_FRONT_MAX, tailw_env));
     int kT = nt;  // first panel of the wide front (nt: none)
     if (tail_env >= 0) kT = std::max(0, nt - 1 - tail_env);
     else if (batch > 20 && batch <= 48) kT = std::max(2048 / GT, nt - 400 / batch);
     auto Fof = [&](int k) { return k >= kT ? Ftail : F0; };
     const int F = Ftail;  // (the largest width: strides of the front's partial sums and counters)
+    if (2 * (size_t)F * batch > sf_split_region_tiles()) {
+        sf_set_error("potrf: dataflow sequence: front %d x %d matrices exceed the partial-sum region", F, batch);
+        return SF_EINVAL;
+    }
     a.front = F;
     for (int d = 1; d <= SF_DF_FRONT_MAX; ++d) a.fstart[d - 1] = d <= F0 ? 0 : kT;
     static const int fp_pos_env = SF_TUNE_INT("SF_DF_FP_POS", -1);
@@ -3913,17 +4002,27 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
 // 96: 37.5 / 38.3, 112: 42.4 / 44.4, 128: 47.1 / 50.7; N = 3008: B = 16 6.15 / 4.7, 64: 11.8 / 11.5, 96: 16.7 / 16.9; N = 2048:
 // B = 16 3.36 / 2.5, 128: 8.15 / 8.1; N = 1024: B = 16 1.29 / 0.88, 256: 2.8 / 3.2 (32 matrices per queue: the dispenser's scan
 // of their chain counters shows)  ->  taken while batch x panels <= 2048 and batch <= 128.
+// sf_persistent_potrf(0): the callers' recovery after a launch that came back SF_INFO_INTERNAL -- from then on every
+// factorisation of the process takes a launch sequence (no waits inside kernels), forced sequence 4 included.
+static std::atomic<int> g_df_enabled{1};
+int sf_set_persistent_potrf(int enable) {
+    return enable < 0 ? g_df_enabled.load() : g_df_enabled.exchange(enable ? 1 : 0);
+}
+static bool sf_potrf_dataflow_fits(int n, int batch) {
+    const int nt = (n + 64 + GT - 1) / GT;  // (panels of the shifted frame at most)
+    return g_df_enabled.load() && nt - 1 <= SF_DF_MAX_STAGES && 2 * (size_t)SF_DF_FRONT_WIDEST * batch <= sf_split_region_tiles();
+}
 static bool sf_potrf_dataflow_auto(int n, int batch) {
     static const int lim = SF_TUNE_INT("SF_DF_BELOW", 2048);
     const int nt = (n + 64 + GT - 1) / GT;  // (panels of the shifted frame at most)
-    return nt - 1 <= SF_DF_MAX_STAGES && (long long)batch * nt <= lim && batch <= 128;
+    return sf_potrf_dataflow_fits(n, batch) && (long long)batch * nt <= lim && batch <= 128;
 }
 int sf_potrf_front_pad(int n, int batch) {
     static const bool off = SF_TUNE_FLAG("SF_NO_FRONT_PAD");  // tuning aid: A/B of the shifted frame
     static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");
     const int sel = g_chol_sequence.load();
     // (a matrix with more panels than the dataflow tables hold takes the fused sequence when the dataflow one is forced)
-    const bool df_fits = (n + 64 + GT - 1) / GT - 1 <= SF_DF_MAX_STAGES;
+    const bool df_fits = sf_potrf_dataflow_fits(n, batch);
     const bool df = sel >= 0 ? (sel == 4 && df_fits) : (!force && sf_potrf_dataflow_auto(n, batch));
     const bool v1 = !df && (sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < SF_UNFUSED_BELOW));  // (as in sf_launch_potrf)
     if (off || v1 || n % GT != 64 || n < 2 * GT) return 0;
@@ -3935,7 +4034,7 @@ int sf_launch_potrf(double* A, int n, int lda, int64_t stride, int batch, int* i
     // The fused panel kernel (128-column panels) is the faster sequence once the batch fills the chip (SF_UNFUSED_BELOW).
     static const char* force = SF_TUNE_STR("SF_CHOL_UNFUSED");  // tuning aid: "1" always unfused, "0" always fused
     const int sel = g_chol_sequence.load();                 // sf_debug_cholesky_sequence(): tests drive both
-    const bool df_fits = (n + 64 + GT - 1) / GT - 1 <= SF_DF_MAX_STAGES;
+    const bool df_fits = sf_potrf_dataflow_fits(n, batch);
     const bool df = sel >= 0 ? (sel == 4 && df_fits) : (!force && sf_potrf_dataflow_auto(n, batch));
     const bool v1 = !df && (sel >= 0 ? sel == 1 : (force ? force[0] == '1' : batch < SF_UNFUSED_BELOW));
     // The wide sequence (panel pairs, one 16-wave workgroup per CU) halves the A-operand stream and a third of all HBM

@@ -361,7 +361,7 @@ class Emulator:
     def from_grid(cls, grid, **pca_kwargs):
         raise NotImplementedError("Emulator.from_grid (PCA of a spectral library) is offline set-up, out of scope")
 
-    def log_likelihood(self):
+    def log_likelihood(self, _retry=True):
         """-(logdet v11 + w_hat^T v11^-1 w_hat) / 2  (Starfish/emulator/emulator.py:602-619), entirely on the device:
         v11 is built from the hyper-parameters by ``sf_emulator_v11_build`` (grid, iPhiPhi and w_hat stay resident), then
         factored and solved by the same batched HIP kernels as the spectrum likelihood (``sf_potrf_batch`` /
@@ -408,6 +408,11 @@ class Emulator:
         _lib.check(lib.sf_logdet_sqmah_batch(D.ptr(A), npad, lda, npad * lda, 1, D.ptr(td["R"]), npad, D.ptr(ws),
                                              ws.numel(), D.ptr(td["out"][0:1]), D.ptr(td["out"][1:2]), s), "sf_logdet_sqmah_batch")
         code = int(td["info"].cpu()[0])
+        if code == D.INFO_INTERNAL:
+            if not _retry:
+                raise RuntimeError(D.INFO_MESSAGES[D.INFO_INTERNAL])
+            D.recover_from_internal(lib, "Emulator.log_likelihood", 1)
+            return self.log_likelihood(_retry=False)  # (A was overwritten: it is rebuilt / re-uploaded above)
         if code != 0:
             raise np.linalg.LinAlgError(f"{code}-th leading minor of the array is not positive definite")
         ld, sq = td["out"].cpu().tolist()

@@ -394,6 +394,8 @@ class SpectrumModel:
             )
         if code == -3:
             raise np.linalg.LinAlgError(D.INFO_MESSAGES[-3])
+        if code == D.INFO_INTERNAL:  # (survived the retry of DeviceOrder.loglike: not a property of the parameters)
+            raise RuntimeError(D.INFO_MESSAGES[D.INFO_INTERNAL])
         if code < 0:
             raise ValueError(D.INFO_MESSAGES.get(code, f"device status {code}"))
 
