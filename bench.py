@@ -438,14 +438,16 @@ def device_note():
         return {"error": str(e)[:80]}
 
 
-def pmc_lookup(tag, kernel_key, total=False):
+def pmc_lookup(tag, kernel_key, total=False, per_step=False):
     """(hbm bytes per launch, source file, collected-on-this-code?) of the latest profiles/r0?_*<tag>*_pmc_summary.json;
-    total: summed over every kernel whose name starts with the key (one launch of each per step)."""
+    total: summed over every kernel whose name starts with the key (one launch of each per step); per_step: the bytes of
+    all launches of one step (hbm_GB_per_step of the panel-kernel aggregate)."""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0[0-9]_*{tag}*_pmc_summary.json")))[-1:]:
         with open(f) as fh:
             summ = json.load(fh)
-        hits = [val["hbm_bytes_per_launch"] for key, val in summ.items()
-                if isinstance(val, dict) and key.lstrip("_").startswith(kernel_key) and "hbm_bytes_per_launch" in val]
+        field = "hbm_GB_per_step" if per_step else "hbm_bytes_per_launch"
+        hits = [val[field] * (1e9 if per_step else 1.0) for key, val in summ.items()
+                if isinstance(val, dict) and key.lstrip("_").startswith(kernel_key) and field in val]
         if hits:
             cid = summ.get("_code_id")
             return (sum(hits) if total else hits[0]), os.path.relpath(f, ROOT) + (f" @code {cid}" if cid else ""), (cid == code_id()) if cid else None
@@ -465,6 +467,16 @@ class Comm:
             self.dist.barrier(group=self.group, device_ids=[self.dev_index])
         else:
             self.dist.barrier()
+
+    def sum(self, x):
+        """After the timed region: a checksum over the ranks' results (host gather of one double per rank)."""
+        if self.dist is None:
+            return float(x)
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
 
     def max(self, x):
         if self.dist is None:
@@ -718,6 +730,9 @@ def main():
     ap.add_argument("--no-cpu-pool", action="store_true", help="cpu_baseline: single-process mode only")
     ap.add_argument("--fill-only", action="store_true",
                     help="run only the HBM-write leg (sf_cov_fill_batch, full dense) and print its object: for rocprofv3 passes")
+    ap.add_argument("--single-scaling", action="store_true",
+                    help="N > 1: only the requested scaling mode, no sub-object for the other one (the 8-rank rehearsal on one "
+                    "GPU: eight full cfg-3 batches would not fit one device)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip other_configs (cfg 3 / cfg 5) and strong_scaling_proxy of the default run")
     args = ap.parse_args()
@@ -801,13 +816,14 @@ def run(args, in_group, rank, local_rank, world, line):
     if not use_dist:
         clock_mhz = t["clock_mhz"]
     lnl_host = t["lnl"]
+    lnl_checksum = comm.sum(float(np.sum(lnl_host)))  # sum of lnL over ALL units of all ranks (strong: = the 1-rank value)
     structured = None
     if n_orders == 1 and not args.no_structured and w.n_local:
         structured = structured_leg(w, args, comm, lnl_host, custom)
 
     # ---- N > 1: the other scaling mode as a sub-object (SURVEY.md 8e split: units of ONE batch over the ranks)
     other_mode, other = None, None
-    if use_dist:
+    if use_dist and not args.single_scaling:
         other_mode = "strong" if args.scaling == "weak" else "weak"
         plist0, order0 = w.plist, w.order0
         w.release()
@@ -819,7 +835,7 @@ def run(args, in_group, rank, local_rank, world, line):
         w2.release()
     default_run = (world == 1 and args.config == "cfg2" and not custom and args.grid == "loguniform"
                    and not args.no_extra_legs)
-    extra, proxy, fill = None, None, None
+    extra, proxy, proxy5, fill = None, None, None, None
     if default_run:
         plist0, order0 = w.plist, w.order0
         base_ms_per_eval = t["ms_per_step"] / w.n_local
@@ -844,7 +860,19 @@ def run(args, in_group, rank, local_rank, world, line):
             extra[name]["workload"] = CONFIGS[name]["label"] + f": {wx.n_orders} order(s) x N_pix={wx.N}, batch={wx.B}"
             extra[name]["ceiling_evals_per_s"] = FP64_MFMA_PEAK_TFLOPS * 1e12 / wx.flops_eval
             wx.release()
-    elif not use_dist:
+        # ... and of cfg 5 (N = 16384, 32 walkers: 16 / 8 / 4 per GPU) -- long chunks are what docs/intro.rst:73 warns about
+        c5 = CONFIGS["cfg5"]
+        ms5 = extra["cfg5"]["ms_per_step"] / c5["batch"]
+        proxy5 = [{"ranks_equivalent": 1, "batch": c5["batch"], "value": extra["cfg5"]["value"],
+                   "ms_per_step": extra["cfg5"]["ms_per_step"], "per_eval_efficiency_vs_full_batch": 1.0}]
+        for g in (2, 4, 8):
+            wp = Workload(dict(c5, batch=c5["batch"] // g), 0, 1, "weak")
+            tp = timed_leg(wp, 2, 1, 1, comm)
+            proxy5.append({"ranks_equivalent": g, "batch": wp.B, "value": tp["value"], "ms_per_step": tp["ms_per_step"],
+                           "per_eval_efficiency_vs_full_batch": ms5 / (tp["ms_per_step"] / wp.n_local),
+                           "panel_frac_of_peak": tp["achieved"] / FP64_MFMA_PEAK_TFLOPS})
+            wp.release()
+    elif not use_dist or args.single_scaling:
         plist0, order0 = w.plist, w.order0
 
     if rank == 0:
@@ -853,7 +881,7 @@ def run(args, in_group, rank, local_rank, world, line):
         # tools/summarize_profile.py; bench.py cannot collect counters itself.
         traffic, traffic_src, traffic_same = (None, None, None)
         if not custom and args.grid == "loguniform":
-            traffic, traffic_src, traffic_same = pmc_lookup(args.config, "k_chol_panel_all")
+            traffic, traffic_src, traffic_same = pmc_lookup(args.config, "k_chol_panel_all", per_step=True)
         ms, prof_steps, achieved = t["ms"], t["prof_steps"], t["achieved"]
         label = cfg["label"] + (" [custom: " + ", ".join(custom) + "]" if custom else "")
         per = " per GPU" if args.scaling == "weak" else " in total"
@@ -890,35 +918,10 @@ def run(args, in_group, rank, local_rank, world, line):
                 "device": device_note(),
             },
             "process_group": pg_note,
+            "lnl_checksum": lnl_checksum,
             "whole_path_tflops": t["value"] * w.flops_eval / 1e12,
             "whole_path_frac_of_mfma_peak": t["value"] * w.flops_eval / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
-            "roofline": {
-                "kernel": "k_chol_panel_w / k_chol_panel / k_potrf_dataflow (fused v_mfma_f64_16x16x4_f64 panel steps of the batched "
-                "Cholesky: long-K update + triangular solves + diagonal-tile update; panel pairs when batch x slabs >= 3400, "
-                "128-column panels for their chain and for medium batches, ONE persistent dataflow launch while batch x "
-                "panels <= 2048)",
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "sustained_clock_mhz": clock_mhz or None,
-                "sustained_clock_note": clock_note if clock_mhz else None,
-                "peak_at_sustained_clock": FP64_MFMA_PEAK_TFLOPS * clock_mhz / 2400.0 if clock_mhz else None,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "traffic_is_this_code": traffic_same,
-                "code_id": code_id(),
-                "note": "rank 0's GPU; the panel launches run on several streams (lookahead chain, slab groups) and overlap: "
-                "`achieved` divides by the UNION of the launch intervals (HIP events, common origin, recorded during the last "
-                "`profiled_steps` of the timed steps); avg_launch_ms is the plain mean launch duration (what rocprofv3 "
-                "--stats reports)",
-                "profiled_steps": prof_steps,
-                "launches": t["launches"],
-                "avg_launch_ms": ms[5] / max(1, t["launches"]),
-                "achieved_by_sum_of_launch_durations": t["gflops"] / (ms[5] * 1e-3) / 1e12 if ms[5] > 0 else None,
-                "algorithmic_flops_per_launch": t["gflops"] / max(1, t["launches"]),
-            },
+            "roofline": None,  # (filled in below: the flat scalars first -- the driver keeps only the first scalar keys)
             "stage_ms_per_step": {
                 k: v / prof_steps
                 for k, v in zip(["transforms", "fill", "panel_union", "potrf_stage", "solve", "panel_launches_sum"], ms)
@@ -926,22 +929,64 @@ def run(args, in_group, rank, local_rank, world, line):
             "potrf_stage_tflops": w.n_local * prof_steps * (N**3 / 3) / (ms[3] * 1e-3) / 1e12 if ms[3] > 0 else None,
             "structured_solver": structured,
         }
+        # ---- roofline: flat scalars FIRST (the driver's record keeps the leading scalar keys and drops nested objects).
+        # `frac` is the WHOLE-PATH figure: algorithmic flops of the path (N^3/3 + 2 m N^2 + N^2 per eval) / step time as
+        # the driver clocks it / the datasheet peak; the panel kernels' own figure (their algorithmic flops / the union of
+        # their HIP-event intervals) is `panel_frac`.
+        whole_tf = t["value"] * w.flops_eval / 1e12 / world
+        alg_bytes_step = 16.0 * N * N * w.n_local  # C written once + read once
+        roof = {"bound": "mfma", "achieved": whole_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": whole_tf / FP64_MFMA_PEAK_TFLOPS, "whole_path_frac": whole_tf / FP64_MFMA_PEAK_TFLOPS,
+                "panel_frac": achieved / FP64_MFMA_PEAK_TFLOPS, "panel_achieved": achieved}
         if fill is not None:
-            out["roofline"]["fill"] = fill  # "the fill stage alone is HBM-write-bound ... report both"
-        if extra is not None:  # scalars of the secondary legs inside `roofline` (the driver keeps this object)
-            out["roofline"]["cfg3_frac"] = extra["cfg3"]["roofline"]["frac"]
-            out["roofline"]["cfg5_frac"] = extra["cfg5"]["roofline"]["frac"]
-            out["roofline"]["cfg3_whole_path_frac"] = extra["cfg3"]["whole_path_frac_of_mfma_peak"]
-            out["roofline"]["cfg5_whole_path_frac"] = extra["cfg5"]["whole_path_frac_of_mfma_peak"]
+            roof["fill_frac"], roof["fill_gbs"] = fill["frac"], fill["achieved"]
+            if fill.get("unaligned"):
+                roof["fill_unaligned_frac"], roof["fill_unaligned_gbs"] = fill["unaligned"]["frac"], fill["unaligned"]["achieved"]
         if proxy is not None:
             for row in proxy[1:]:
-                out["roofline"][f"b{row['batch']}_efficiency"] = row["per_eval_efficiency_vs_full_batch"]
+                roof[f"b{row['batch']}_efficiency"] = row["per_eval_efficiency_vs_full_batch"]
+        if extra is not None:
+            roof["cfg3_frac"] = extra["cfg3"]["whole_path_frac_of_mfma_peak"]
+            roof["cfg5_frac"] = extra["cfg5"]["whole_path_frac_of_mfma_peak"]
+            roof["cfg3_panel_frac"] = extra["cfg3"]["roofline"]["frac"]
+            roof["cfg5_panel_frac"] = extra["cfg5"]["roofline"]["frac"]
+        if proxy5 is not None:
+            for row in proxy5[1:]:
+                roof[f"cfg5_b{row['batch']}_efficiency"] = row["per_eval_efficiency_vs_full_batch"]
+        roof["traffic"] = traffic
+        roof["traffic_ratio"] = traffic / alg_bytes_step if traffic else None  # counter bytes per step / 16 N^2 B
+        roof["traffic_is_this_code"] = traffic_same
+        roof["sustained_clock_mhz"] = clock_mhz or None
+        roof["peak_at_sustained_clock"] = FP64_MFMA_PEAK_TFLOPS * clock_mhz / 2400.0 if clock_mhz else None
+        roof["profiled_steps"] = prof_steps
+        roof["launches"] = t["launches"]
+        roof["avg_launch_ms"] = ms[5] / max(1, t["launches"])
+        roof["achieved_by_sum_of_launch_durations"] = t["gflops"] / (ms[5] * 1e-3) / 1e12 if ms[5] > 0 else None
+        roof["algorithmic_flops_per_launch"] = t["gflops"] / max(1, t["launches"])
+        roof["algorithmic_bytes_per_step"] = alg_bytes_step
+        roof["code_id"] = code_id()
+        roof["traffic_source"] = traffic_src
+        roof["sustained_clock_note"] = clock_note if clock_mhz else None
+        roof["kernel"] = ("k_chol_panel_w / k_chol_panel / k_potrf_dataflow (fused v_mfma_f64_16x16x4_f64 panel steps of the batched "
+                          "Cholesky: long-K update + triangular solves + diagonal-tile update; panel pairs when batch x slabs >= 3400, "
+                          "128-column panels for their chain and for medium batches, ONE persistent dataflow launch while batch x "
+                          "panels <= 2048)")
+        roof["note"] = ("`frac` / `achieved`: whole path -- algorithmic flops of every stage / the timed step; `panel_frac` / "
+                        "`panel_achieved`: rank 0's panel launches, which run on several streams (lookahead chain, slab groups) and "
+                        "overlap: their algorithmic flops / the UNION of the launch intervals (HIP events on the launch streams, common "
+                        "origin, recorded during the last `profiled_steps` of the timed steps); avg_launch_ms is the plain mean launch "
+                        "duration (what rocprofv3 --stats reports); `traffic` = HBM bytes per step from the rocprofv3 --pmc passes "
+                        "under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE), traffic_ratio = traffic / algorithmic_bytes_per_step")
+        if fill is not None:
+            roof["fill"] = fill  # "the fill stage alone is HBM-write-bound ... report both"
+        out["roofline"] = roof
         if other is not None:
             out[other_mode] = other
         if proxy is not None:
             out["strong_scaling_proxy"] = {
                 "note": "1-GPU proxy of the strong split (SURVEY.md 8e: 128/G walkers per GPU): cfg 2 at the per-rank batch "
-                "of G ranks, 5 timed steps each", "rows": proxy}
+                "of G ranks, 5 timed steps each", "rows": proxy,
+                "cfg5_rows": proxy5, "cfg5_note": "the same for cfg 5 (N = 16384): 32 / G walkers per GPU, 2 timed steps each"}
         if extra is not None:
             out["other_configs"] = extra
         if world == 1 and args.cpu_sample > 0 and plist0:

@@ -179,6 +179,8 @@ def load():
 
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("SF_LIB_PATH") and not hasattr(lib, name):
+            continue  # (development hook only: an OLDER build of the library in a same-box A/B lacks the newest entry points)
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -54,8 +54,10 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_shard_real_models(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_shard_real_models(tmp_path, world):
+    """world = 8: the rank count of the BASELINE metric's last column -- eight processes, eight contexts on the one GPU of
+    the test box (11 walkers -> one or two per rank: every rank's call is a persistent-kernel launch of 1-2 matrices)."""
     ctx = mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
     # bounded wait: a wedged N > 1 path fails the test (it must not wedge the suite, and it must not pass as a skip)
     import time
@@ -69,7 +71,7 @@ def test_two_ranks_shard_real_models(tmp_path):
     if not done:
         for p in ctx.processes:
             p.terminate()
-        pytest.fail("the two GPU worker processes did not finish within 300 s: the N > 1 path hangs")
+        pytest.fail(f"the {world} GPU worker processes did not finish within 300 s: the N > 1 path hangs")
     # the same evaluations in this process, unsharded
     o = synth.make_order(N=512, m=4, seed=21)
     want = synth.build_model(o).log_likelihood_batch(synth.walker_ball(o, B=11, seed=4))
@@ -123,14 +125,16 @@ def _cfg4_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_cfg4_order_major_split_two_ranks_vs_reference_goldens(tmp_path):
-    """cfg 4 = cfg 3 sharded: 25 orders x N = 3000, the three golden walkers, two ranks; the gathered per-order lnL
+@pytest.mark.parametrize("world", [2, 8])
+def test_cfg4_order_major_split_vs_reference_goldens(tmp_path, world):
+    """cfg 4 = cfg 3 sharded: 25 orders x N = 3000, the three golden walkers, two ranks -- and EIGHT, the rank count cfg 4
+    names (75 units -> 9 or 10 per rank, every rank builds only the 4-5 orders it owns); the gathered per-order lnL
     must equal the REFERENCE's per-order values (tests/golden/model_cfg3.npz) and their sum the model lnL."""
     import time
 
     from conftest import load_golden
+    from starfish_amd.parallel import order_major_slices, shard_range
 
-    world = 2
     ctx = mp.spawn(_cfg4_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
     deadline = time.time() + 600
     done = False
@@ -141,7 +145,7 @@ def test_cfg4_order_major_split_two_ranks_vs_reference_goldens(tmp_path):
     if not done:
         for p in ctx.processes:
             p.terminate()
-        pytest.fail("the two GPU worker processes did not finish within 600 s: the N > 1 path hangs")
+        pytest.fail(f"the {world} GPU worker processes did not finish within 600 s: the N > 1 path hangs")
     g = load_golden("model_cfg3.npz")
     want = g["lnl"]
     for r in range(world):
@@ -149,6 +153,13 @@ def test_cfg4_order_major_split_two_ranks_vs_reference_goldens(tmp_path):
         assert got.shape == want.shape
         assert np.all(np.abs(got - want) <= 1e-8 * np.abs(want) + 1e-8), np.max(np.abs(got - want) / np.abs(want))
         np.testing.assert_allclose(got.sum(axis=0), want.sum(axis=0), rtol=1e-9)
-    # order-major: rank 0 owns orders 0..12 (12 shared with rank 1), rank 1 owns 12..24
-    o0, o1 = np.load(tmp_path / "cfg4_owned_0.npy"), np.load(tmp_path / "cfg4_owned_1.npy")
-    assert o0.tolist() == list(range(13)) and o1.tolist() == list(range(12, 25))
+    # order-major: with two ranks rank 0 owns orders 0..12 (12 shared with rank 1), rank 1 owns 12..24
+    owned = [np.load(tmp_path / f"cfg4_owned_{r}.npy").tolist() for r in range(world)]
+    if world == 2:
+        assert owned[0] == list(range(13)) and owned[1] == list(range(12, 25))
+    n_orders, B = want.shape
+    for r in range(world):
+        lo, hi = shard_range(n_orders * B, r, world)
+        assert owned[r] == [o for o, _, _ in order_major_slices(n_orders, B, lo, hi)]
+        assert owned[r] == list(range(owned[r][0], owned[r][-1] + 1)) and len(owned[r]) <= -(-n_orders // world) + 1
+    assert owned[0][0] == 0 and owned[-1][-1] == n_orders - 1
