@@ -3241,12 +3241,6 @@ struct sf_df_args {
     int fstart[SF_DF_FRONT_MAX];        // first panel whose front is d slabs wide (index d - 1): chain_next[.][d - 1] counts from there
     int thr_base[2][2][SF_DF_FRONT_MAX];  // [table][panel parity][d - 1]: partial-sum arrivals of that parity before distance d existed
     int fp_pos;       // position of the front partial sums inside a stage's segment, in 1/256 of its rest tasks
-    // round 5: the partial sums of the chain and of the front, FP(b, k, d, .), are not queued but claimed when ready, like the
-    // chain tasks (fp1_next[b][d - 1]: (panel - fp1_first[table][d - 1]) << 4 | split of the next one).  In the queue they were drawn when the queue's
-    // workgroups had worked their way through the long-K rest tasks in front of them: 27-316 us of idle chain per panel at 16
-    // matrices (profiles/r04_s_dataflow_chain_b16.txt), although their inputs are two stages old.
-    int fp1_dyn, fp1_first[2][SF_DF_FRONT_WIDEST];  // [table][d - 1]: first panel with partial sums for distance d
-    int* fp1_next;                                  // [batch][SF_DF_FRONT_WIDEST]
     int bq[2], ntasks[2];  // table v serves the queues with bq[v] matrices
     int pt_cap;       // largest split of the front partial sums: a (matrix, front slab) owns pt_cap tiles per panel parity in region 2
     int *head, *abort_flag, *done_top, *done_D, *done_row, *row_L, *fp_cnt, *rp_cnt, *stage_done;
@@ -3316,43 +3310,6 @@ __device__ SF_DF_HELPER bool sf_df_try_chain(sf_df_kargs& a, const int qx, int& 
     return false;
 }
 
-// The next partial-sum task FP(b, k, d, s) of a chain / front slab of queue qx whose inputs are there (rows k and k+d through
-// panel k-2 with their diagonal tiles' updates; the partial-sum slots' previous reader -- the front task of (b, k-2, d) --
-// done)?  cb = matrix, ck = panel, cs = split | d << 8.  One lane.
-__device__ SF_DF_HELPER bool sf_df_try_fp1(sf_df_kargs& a, const int qx, int& cb, int& ck, int& cs) {
-    if (!a.fp1_dyn) return false;
-#ifdef SF_EXP_NOFP1
-    return false;
-#endif
-    const int nt = a.nt;
-    const int Bq = (a.batch - qx + SF_DF_QUEUES - 1) / SF_DF_QUEUES;
-    const int vq = Bq == a.bq[0] ? 0 : 1;
-    const int F = min(a.front, SF_DF_FRONT_WIDEST);
-    for (int d = 1; d <= F; ++d) {  // (the chain's own first)
-        for (int j = 0; j < Bq; ++j) {
-            const int b1 = qx + SF_DF_QUEUES * j;
-            int* ctr = a.fp1_next + SF_DF_FRONT_WIDEST * b1 + d - 1;
-            const int v = sf_df_load(ctr);
-            const int k = a.fp1_first[vq][d - 1] + (v >> 4), sp = v & 15;
-            if (k + d > nt - 1) continue;  // (every one of them is claimed)
-            const int* drow = a.done_row + (size_t)b1 * nt;
-            if (sf_df_load(drow + k) < k - 1) continue;
-            if (sf_df_load(drow + k + d) < k - 1) continue;
-            if (d == 1 ? sf_df_load(a.done_D + b1) < k : sf_df_load(drow + k + d - 2) < k - 1) continue;
-            const int St = a.st[vq][k - 1].split & 15;  // (> 0 from fp1_first on: the K range only grows)
-            int expect = v;
-            if (__hip_atomic_compare_exchange_strong(ctr, &expect, sp + 1 < St ? v + 1 : ((v >> 4) + 1) << 4, __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                cb = b1;
-                ck = k;
-                cs = sp | (d << 8);
-                return true;
-            }
-        }
-    }
-    return false;
-}
-
 template <bool RHS>
 __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in) {
     extern __shared__ __attribute__((aligned(16))) double dsm[];
@@ -3406,8 +3363,6 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 auto try_chain = [&](int qx) { return SF_DF_MISS_CLAIMS(visited < SF_DF_QUEUES) ? false : sf_df_try_chain(a, qx, cb, ck, cd); };
                 if (try_chain(qcur)) {
                     t = -3;
-                } else if (sf_df_try_fp1(a, qcur, cb, ck, cd)) {
-                    t = -6;
                 } else if (visited < SF_DF_QUEUES) {
                     t = ntasks > 0 ? __hip_atomic_fetch_add(a.head + qcur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ntasks;
                     if (t >= ntasks) t = -4;  // this queue is exhausted
@@ -3417,9 +3372,6 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     for (int qx = 0; qx < SF_DF_QUEUES && t == -2; ++qx)
                         if (try_chain(qx)) {
                             t = -3;
-                            s_ints[5] = 0;
-                        } else if (sf_df_try_fp1(a, qx, cb, ck, cd)) {
-                            t = -6;
                             s_ints[5] = 0;
                         }
                     if (t == -2) {
@@ -3478,22 +3430,13 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
             k = chain_k;
             d = chain_d;
             i = k + d;
-        } else if (t == -6) {  // partial sums of the chain / the front, claimed when ready: FP(b, k, d, sp)
-            type = T_FP;
-            bchain = chain_b;
-            k = chain_k;
-            sp = chain_d & 255;
-            d = chain_d >> 8;
-            i = k + d;
-            const int vq = ((a.batch - (chain_b & (SF_DF_QUEUES - 1)) + SF_DF_QUEUES - 1) / SF_DF_QUEUES) == a.bq[0] ? 0 : 1;
-            S = a.st[vq][k - 1].split & 15;
         } else {
             while (kst + 1 < nt - 1 && t >= a.st[v][kst + 1].off) ++kst;
             const sf_df_stage st = sf_df_stage_of(a.st[v][kst]);
             // front slabs of panel kst + 1 that exist, front slabs d >= 2 of this panel, ordinary slabs of this panel
             const int Fk = st.fw & 255, nF = st.fw >> 8;
             const int nord = max(0, nt - kst - 1 - Fk);
-            const int n_fp = a.fp1_dyn ? 0 : B * nF * st.St;  // (with fp1_dyn they are claimed when ready, not queued)
+            const int n_fp = B * nF * st.St;
             const int n_r1 = B * nord * (st.Sr > 1 ? st.Sr : 1);
             // segment: fp_pos/256 of the rest tasks, the front partial sums of the NEXT panel, the other rest tasks, the reduces.
             // (FP tasks at the very front of the segment are claimed while the two rows they read are still being finished by
@@ -3706,11 +3649,8 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                                             int cb = 0, ck = 0, cd = 1;
                                             for (int x = 0; x < SF_DF_QUEUES; ++x) {
                                                 const int qx = (qcur + x) & (SF_DF_QUEUES - 1);
-                                                int code = 0;
-                                                if (sf_df_try_chain(a, qx, cb, ck, cd)) code = -3;
-                                                else if (sf_df_try_fp1(a, qx, cb, ck, cd)) code = -6;  // ... or one of the chains' partial sums
-                                                if (code) {
-                                                    s_ints[0] = code;
+                                                if (sf_df_try_chain(a, qx, cb, ck, cd)) {
+                                                    s_ints[0] = -3;
                                                     s_ints[2] = cb;
                                                     s_ints[3] = ck;
                                                     s_ints[4] = cd;
@@ -3719,7 +3659,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                                             }
                                             return false;
                                         },
-                                        t >= 0);  // (a task claimed when ready is never set aside)
+                                        true);
             if (wr == SF_DF_DEFERRED) {  // a chain task first (claimed in the wait), then this task again
                 pend_t = t;
                 resume = 1;
@@ -3823,7 +3763,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     // counters: in the two inverse-tile buffers of the launch sequences (2 x batch x sW doubles), which this sequence does not use
     int* flags = (int*)Wt2;
     const size_t ndbg = 2 * (16 * SF_CHIP_WGS + 16 * 64 + 8 * 64);
-    const size_t nflags = 64 + (size_t)batch * (3 * nt + 2 + SF_DF_FRONT_WIDEST + 3 * SF_DF_FRONT_MAX) + (size_t)SF_DF_QUEUES * nt + 8 + ndbg;
+    const size_t nflags = 64 + (size_t)batch * (3 * nt + 2 + 3 * SF_DF_FRONT_MAX) + (size_t)SF_DF_QUEUES * nt + 8 + ndbg;
     // (region 2 of `part` holds 2 x front x batch x pt_cap tiles with pt_cap >= 1: batches beyond what it holds at the widest
     // front are refused here -- the automatic choice stops at 128 matrices, a forced sequence 4 falls back in sf_launch_potrf)
     if (nt - 1 > SF_DF_MAX_STAGES || nflags * sizeof(int) > 2 * (size_t)batch * sW * sizeof(double) ||
@@ -3842,7 +3782,6 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.row_L = a.done_row + (size_t)batch * nt;
     a.rp_cnt = a.row_L + (size_t)batch * nt;
     a.stage_done = a.rp_cnt + (size_t)batch * nt;  // [SF_DF_QUEUES][nt]
-    a.fp1_next = a.stage_done + (size_t)SF_DF_QUEUES * nt;  // [batch][SF_DF_FRONT_WIDEST]
     SF_HIP(hipMemsetAsync(flags, 0, nflags * sizeof(int), s));
     SF_HIP(hipMemsetAsync(info, 0, sizeof(int) * (size_t)batch, s));
 #ifdef SF_TUNING
@@ -3901,8 +3840,6 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.front = F;
     for (int d = 1; d <= SF_DF_FRONT_MAX; ++d) a.fstart[d - 1] = d <= F0 ? 0 : kT;
     static const int fp_pos_env = SF_TUNE_INT("SF_DF_FP_POS", -1);
-    static const int fp1_env = SF_TUNE_INT("SF_DF_FP1_DYN", -1);  // (tuning aid: 0 = the chain's partial sums queued as in round 4)
-    a.fp1_dyn = (fp1_env >= 0 ? (fp1_env ? 1 : 0) : 1) && F <= SF_DF_FRONT_WIDEST;
     a.fp_pos = fp_pos_env >= 0 ? fp_pos_env : 256;  // (0 / 64 / 128 / 192 / 256: B = 16 7.75 / 7.7 / 7.6 / 7.7 / 7.55 ms, B = 32 13.8 / 13.9 / 13.75 / 13.7 / 13.65)
     a.nt = nt;
     a.batch = batch;
@@ -3965,20 +3902,14 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
                 last_split[k & 1] = k;
             }
             st.thr_rp = thr_rp;
-            off += (a.fp1_dyn ? 0 : B * nF * st.St) + B * nord * (st.Sr > 1 ? st.Sr + 1 : 1);
+            off += B * nF * st.St + B * nord * (st.Sr > 1 ? st.Sr + 1 : 1);
         }
         a.ntasks[v] = off;
-        for (int d = 1; d <= SF_DF_FRONT_WIDEST; ++d) {
-            a.fp1_first[v][d - 1] = nt;  // first panel whose front slab d has partial sums (nt: none)
-            for (int k = nt - 1 - d; k >= 1; --k)
-                if (tab[v][k - 1].St > 0 && d <= (tab[v][k - 1].fw >> 8)) a.fp1_first[v][d - 1] = k;
-        }
     }
     if (a.bq[1] == a.bq[0]) {
         for (int k = 0; k + 1 < nt; ++k) tab[1][k] = tab[0][k];
         for (int par = 0; par < 2; ++par)
             for (int d = 0; d < SF_DF_FRONT_MAX; ++d) a.thr_base[1][par][d] = a.thr_base[0][par][d];
-        for (int d = 0; d < SF_DF_FRONT_WIDEST; ++d) a.fp1_first[1][d] = a.fp1_first[0][d];
     }
     for (int v = 0; v < 2; ++v)
         for (int k = 0; k + 1 < nt; ++k) a.st[v][k] = sf_df_pack(tab[v][k]);
