@@ -1912,7 +1912,15 @@ struct sf_panelw_args {
     int64_t sY;
     int ldy, mpad, nt128;
     int fp;            // shifted frame, see sf_panel_args
+#ifdef SF_TUNING
+    long long* stamps; // tuning builds (SF_WIDE_STAMPS): 100 MHz wall-clock stamps of the phases of workgroup gridDim.x / 2
+#endif
 };
+#ifdef SF_TUNING
+#define SF_W_STAMP(i) do { if (g.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g.stamps[i] = wall_clock64(); } while (0)
+#else
+#define SF_W_STAMP(i)
+#endif
 
 template <bool RHS>
 __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
@@ -1941,6 +1949,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
     const bool wave_live = wm * 32 < rows_here;
 
     sf_d4 acc[TM][TN];
+    SF_W_STAMP(0);
     // ---------------------------------------------------------------- 1: long-K update
     {
         typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -2027,6 +2036,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
             for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(acc[mi][ni][r]));
+        SF_W_STAMP(1);
 
         // fragment reads (layout and swizzle of k_chol_panel; sf_swz of a fragment row depends on l15 only)
         const int sw = sf_swz(l15);
@@ -2134,7 +2144,9 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
         }
     };
     __syncthreads();  // (the main loop's last reads of the ring are done)
+    SF_W_STAMP(2);
     solve(g.Wt0, std::integral_constant<int, 0>());
+    SF_W_STAMP(3);
 
     // 2b: T2 -= L1 L21^T, 32 columns of L1 at a time (chunk q = the blocks of the waves wn == q)
     {
@@ -2182,7 +2194,9 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
             }
         }
     }
+    SF_W_STAMP(4);
     solve(g.Wt1, std::integral_constant<int, 2>());
+    SF_W_STAMP(5);
 
     // ---------------------------------------------------------------- 3: L in place, rhs -= L z
     {
@@ -2219,6 +2233,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
         }
     }
 
+    SF_W_STAMP(6);
     // ---------------------------------------------------------------- 4: S = C[slab, slab] - L L^T, K = 256
     // L is taken from the accumulators through ONE LDS image per panel (Ts, 128 x 128, row stride 130: the operand reads of
     // a wave instruction hit distinct 8-byte banks per half wave), not read back from global memory: the 36 lower blocks
@@ -2280,6 +2295,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
                     acc2[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[ks * 4], Pb[ks * 4], acc2[j], 0, 0, 1);  // neg:[1,0,0]
             }
         }
+        SF_W_STAMP(7);
         const bool parked = g.Sout && sl == 0;  // (only the first slab of a launch is the next diagonal tile)
         double* So = parked ? g.Sout + (int64_t)b * g.sS : Cb + (int64_t)row0 * g.lda + row0;
         const int ldo = parked ? g.ldS : g.lda;
@@ -2315,6 +2331,13 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
         if (tid < rows_here)
             g.rhs[(int64_t)b * g.ldr + row0 + tid] -= (red[tid] + red[GT + tid]) + (red[2 * GT + tid] + red[3 * GT + tid]);
     }
+#ifdef SF_TUNING
+    if (g.stamps) {
+        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SF_W_STAMP(8);
+    }
+#endif
 #undef WBC
 }
 
@@ -2781,7 +2804,8 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
 // tail_rounds: the pairs whose wide launches have at most this many rounds of workgroups left (and everything after them)
 // are single narrow steps; -1 = wide to the end; -2 = switch half-way (test aid: exercises the hand-over on any size).
 static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
-                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex, int tail_rounds, int fp) {
+                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex, int tail_rounds, int fp,
+                              int head_panels = 0) {
     if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
         sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
         return SF_EINVAL;
@@ -2877,6 +2901,14 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         SF_LAUNCH_CHECK();
         return SF_OK;
     };
+#ifdef SF_TUNING
+    long long* wstamps = nullptr;
+    int wstamp_n = 0, wstamp_k[64];
+    if (SF_TUNE_FLAG("SF_WIDE_STAMPS")) {
+        SF_HIP(hipHostMalloc((void**)&wstamps, sizeof(long long) * 16 * 64));
+        for (int i = 0; i < 16 * 64; ++i) wstamps[i] = 0;
+    }
+#endif
     auto wide = [&](int k, int slab0, int nslab, int step, bool park, hipStream_t st) -> int {
         sf_panelw_args g = {};
         g.C = A;
@@ -2911,6 +2943,12 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
             sf_set_error("panel grid too large");
             return SF_EINVAL;
         }
+#ifdef SF_TUNING
+        if (wstamps && wstamp_n < 64) {
+            wstamp_k[wstamp_n] = k * 1000 + nslab;
+            g.stamps = wstamps + 16 * wstamp_n++;
+        }
+#endif
         double rows = 0.0;
         for (int i = 0; i < nslab; ++i) rows += (n - (slab0 + i * step) * GT < GT) ? n - (slab0 + i * step) * GT : GT;
         // algorithmic flops of the two panel steps it replaces: update 2 k0 rows 128 (+ 128 more K for the second panel),
@@ -2951,7 +2989,48 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
     // take over earlier (`tail_rounds`): the timeline suggested that the last pairs -- few rounds of ~1 ms workgroups,
     // every dependency of the chain costs a round -- would be better off as narrow steps, the measurement says no
     // (cfg 2: wide to the end 49.3 ms, hand-over with 2 / 5 / 8 / 12 rounds left 50.0 / 50.4 / 51.0 / 51.8, narrow 51.5).
+    // One narrow step of the chain + both slab groups: panel k as D(k), top(k), rest(k) -- the steps before the first pair
+    // (`head`) and after the last one.
+    auto narrow_step = [&](int k) -> int {
+        const int k0 = k * GT;
+        const int pw = (n - k0 < GT) ? n - k0 : GT;
+        if (e_A) {  // the tile parked by the last wide A launch, and the rows of its two slabs
+            SF_HIP(hipStreamWaitEvent(c, e_A, 0));
+            for (int g = 0; g < 2; ++g) SF_HIP(hipStreamWaitEvent(bs[g], e_A, 0));
+            e_A = nullptr;
+        }
+        SF_TRY(wait_readers(k & 3));
+        SF_TRY(diag(k));
+        if (k + 1 >= nt) return SF_OK;
+        hipEvent_t e_d;
+        SF_TRY(sf_exec_event(ex, &e_d));
+        SF_HIP(hipEventRecord(e_d, c));
+        // top(k): the slab of the next diagonal tile, on the chain; its rows were finished by the group of its parity
+        if (e_last[(k + 1) & 1]) SF_HIP(hipStreamWaitEvent(c, e_last[(k + 1) & 1], 0));
+        SF_TRY(narrow(k0, pw, (k + 1) * GT, 1, 1, Wslot(k), true, c, 0));
+        for (int g = 0; g < 2; ++g) {
+            int first = k + 2;
+            if ((first & 1) != g) ++first;
+            if (first >= nt) continue;
+            const int cnt = (nt - 1 - first) / 2 + 1;
+            SF_HIP(hipStreamWaitEvent(bs[g], e_d, 0));
+            SF_TRY(narrow(k0, pw, first * GT, cnt, 2, Wslot(k), false, bs[g], 1 + g));
+            SF_TRY(sf_exec_event(ex, &e_last[g]));
+            SF_HIP(hipEventRecord(e_last[g], bs[g]));
+            readers[k & 3].push_back(e_last[g]);
+        }
+        return SF_OK;
+    };
+    // The first pairs have short K loops: a wide workgroup (one per CU) is then mostly its epilogue -- tile in, two
+    // triangular solves, tile out, one after the other with nothing beside it on the CU (B = 128: pair 0 runs at 0.44 of
+    // the matrix peak, pair 1 at 0.65, pair 2 at 0.70; the pairs from K = 1024 on at 0.81-0.88,
+    // profiles/r05_d_wide_per_pair_b128.txt).  The panels left of `head` are narrow steps (two workgroups per CU overlap
+    // one's memory phases with the other's solves).
+    static const int head_env = SF_TUNE_INT("SF_WIDE_HEAD", -1);
+    const int head = std::min(nt, (head_env >= 0 ? head_env : head_panels) & ~1);
     int k = 0;
+    for (; k < head; ++k) SF_TRY(narrow_step(k));
+    bool handover = head > 0;
     for (; k < nt; k += 2) {
         if (k + 2 >= nt) break;  // no rows below the pair: the narrow loop finishes the diagonal block
         const long long rounds_left = (long long)batch * (nt - (k + 4) > 0 ? nt - (k + 4) : 0) / 256;
@@ -2959,6 +3038,11 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         if (tail_rounds == -2 && k >= (nt / 4) * 2 && k > 0) break;
         // chain(p): needs the tile parked by A(p-1) and the rows of slab k+1 (A(p-1))
         if (e_A) SF_HIP(hipStreamWaitEvent(c, e_A, 0));
+        if (handover) {  // (after narrow steps: the rows of slab k+1 come from the slab group of its parity)
+            for (int g = 0; g < 2; ++g)
+                if (e_last[g]) SF_HIP(hipStreamWaitEvent(c, e_last[g], 0));
+            handover = false;
+        }
         SF_TRY(wait_readers(k & 3));
         SF_TRY(diag(k));
         SF_TRY(narrow(k * GT, GT, (k + 1) * GT, 1, 1, Wslot(k), true, c, 0));  // (rows below the pair exist: panel k is full)
@@ -2992,41 +3076,27 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
         }
     }
     // narrow tail (also: a trailing single panel, pairs without rows below them)
-    for (; k < nt; ++k) {
-        const int k0 = k * GT;
-        const int pw = (n - k0 < GT) ? n - k0 : GT;
-        if (e_A) {  // the tile parked by the last wide A launch, and the rows of its two slabs
-            SF_HIP(hipStreamWaitEvent(c, e_A, 0));
-            for (int g = 0; g < 2; ++g) SF_HIP(hipStreamWaitEvent(bs[g], e_A, 0));
-            e_A = nullptr;
-        }
-        SF_TRY(wait_readers(k & 3));
-        SF_TRY(diag(k));
-        if (k + 1 >= nt) break;
-        hipEvent_t e_d;
-        SF_TRY(sf_exec_event(ex, &e_d));
-        SF_HIP(hipEventRecord(e_d, c));
-        // top(k): the slab of the next diagonal tile, on the chain; its rows were finished by the group of its parity
-        if (e_last[(k + 1) & 1]) SF_HIP(hipStreamWaitEvent(c, e_last[(k + 1) & 1], 0));
-        SF_TRY(narrow(k0, pw, (k + 1) * GT, 1, 1, Wslot(k), true, c, 0));
-        for (int g = 0; g < 2; ++g) {
-            int first = k + 2;
-            if ((first & 1) != g) ++first;
-            if (first >= nt) continue;
-            const int cnt = (nt - 1 - first) / 2 + 1;
-            SF_HIP(hipStreamWaitEvent(bs[g], e_d, 0));
-            SF_TRY(narrow(k0, pw, first * GT, cnt, 2, Wslot(k), false, bs[g], 1 + g));
-            SF_TRY(sf_exec_event(ex, &e_last[g]));
-            SF_HIP(hipEventRecord(e_last[g], bs[g]));
-            readers[k & 3].push_back(e_last[g]);
-        }
-    }
+    for (; k < nt; ++k) SF_TRY(narrow_step(k));
     hipEvent_t e_join;
     SF_TRY(sf_exec_event(ex, &e_join));
     SF_HIP(hipEventRecord(e_join, c));
     SF_HIP(hipStreamWaitEvent(s, e_join, 0));
     if (e_A) SF_HIP(hipStreamWaitEvent(s, e_A, 0));
     if (e_last[1]) SF_HIP(hipStreamWaitEvent(s, e_last[1], 0));
+#ifdef SF_TUNING
+    if (wstamps) {  // (synchronises: phases of one workgroup per wide launch, us)
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "wide launches, workgroup grid/2: k nslab | prologue | K loop | solve 1 | 2b | solve 2 | store + rhs | S load + step 4 | S store + drain | total (us)\n");
+        for (int i = 0; i < wstamp_n; ++i) {
+            const long long* t = wstamps + 16 * i;
+            fprintf(stderr, "%2d %2d |", wstamp_k[i] / 1000, wstamp_k[i] % 1000);
+            const int seg[8][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}};
+            for (auto& sg : seg) fprintf(stderr, " %7.1f |", (t[sg[1]] - t[sg[0]]) / 100.0);
+            fprintf(stderr, " %7.1f\n", (t[8] - t[0]) / 100.0);
+        }
+        (void)hipHostFree(wstamps);
+    }
+#endif
     return SF_OK;
 }
 

@@ -648,9 +648,10 @@ __global__ __launch_bounds__(256, 4) void k_fill_dense_plain(sf_fill_args a, int
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_fill_dense_band(sf_fill_args a, int nt, int G,
-                                                            const unsigned short* __restrict__ list,
-                                                            const int* __restrict__ count) {
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void k_fill_dense_band(sf_fill_args a, int nt, int G,
+                                                              const unsigned short* __restrict__ list,
+                                                              const int* __restrict__ count) {
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int cnt = count[b];
     const unsigned short* __restrict__ l = list + (int64_t)b * nt * nt;
@@ -724,8 +725,11 @@ int sf_launch_fill_dense(const sf_fill_args& a, int B, unsigned char* smap, unsi
         sb = ex->aux;
         SF_HIP(hipEventRecord(e_map, s));
         SF_HIP(hipStreamWaitEvent(sb, e_map, 0));
-        const int G = 32;
-        hipLaunchKernelGGL(k_fill_dense_band, dim3((unsigned)B * G), dim3(256), 0, sb, a2, nt, G, list, count);
+        static const int G = SF_TUNE_INT("SF_FILL_BAND_G", 32);
+        static const int occ = SF_TUNE_INT("SF_FILL_BAND_OCC", 2);
+        if (occ == 4) hipLaunchKernelGGL(k_fill_dense_band<4>, dim3((unsigned)B * G), dim3(256), 0, sb, a2, nt, G, list, count);
+        else if (occ == 3) hipLaunchKernelGGL(k_fill_dense_band<3>, dim3((unsigned)B * G), dim3(256), 0, sb, a2, nt, G, list, count);
+        else hipLaunchKernelGGL(k_fill_dense_band<2>, dim3((unsigned)B * G), dim3(256), 0, sb, a2, nt, G, list, count);
         SF_LAUNCH_CHECK();
         SF_HIP(hipEventRecord(e_band, sb));
     }
@@ -756,7 +760,7 @@ int sf_launch_fill_dense(const sf_fill_args& a, int B, unsigned char* smap, unsi
         SF_HIP(hipStreamWaitEvent(s, e_band, 0));
     } else if (structured) {
         const int G = 32;
-        hipLaunchKernelGGL(k_fill_dense_band, dim3((unsigned)B * G), dim3(256), 0, s, a2, nt, G, list, count);
+        hipLaunchKernelGGL(k_fill_dense_band<2>, dim3((unsigned)B * G), dim3(256), 0, s, a2, nt, G, list, count);
         SF_LAUNCH_CHECK();
     }
     return SF_OK;

@@ -20,6 +20,15 @@ def _run(argv, env=None, timeout=600):
     return subprocess.run([sys.executable, BENCH] + argv, capture_output=True, text=True, env=e, timeout=timeout)
 
 
+def _line(r):
+    """The one JSON line of a bench run; a failed run's `error` field (and the end of stderr) in the assertion message."""
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-800:], r.stderr[-800:])
+    d = json.loads(lines[0])
+    assert r.returncode == 0 and "error" not in d, (d.get("error"), r.stderr[-1200:])
+    return d
+
+
 def _gpus():
     import torch
 
@@ -230,27 +239,20 @@ def test_eight_rank_rehearsal_on_one_gpu_cfg2_strong_and_cfg4():
     hook = {"SF_BENCH_RANKS_SHARE_GPU": "1", "OMP_NUM_THREADS": "4"}
     r = _run(["--gpus", "8", "--scaling", "strong", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-structured"],
              env=hook, timeout=1500)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0 and "error" not in d
+    d = _line(r)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["global_batch"] == 128 and d["config"]["units_per_gpu"] == 16
     wk = d["weak"]
     assert wk["n_gpus"] == 8 and wk["global_batch"] == 8 * 128 and wk["units_per_gpu"] == 128 and wk["value"] > 0
     # the 128 walkers of the strong split are the walkers of the one-rank batch: same sum of lnL (16 matrices per call
     # instead of 128: another launch sequence, equal to rounding)
     one = _run(["--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-structured", "--no-extra-legs"], timeout=900)
-    assert one.returncode == 0, one.stderr[-2000:]
-    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    d1 = _line(one)
     assert d1["n_gpus"] == 1 and abs(d["lnl_checksum"] - d1["lnl_checksum"]) <= 1e-11 * abs(d1["lnl_checksum"])
 
     r = _run(["--gpus", "8", "--config", "cfg3", "--scaling", "strong", "--single-scaling", "--steps", "1", "--warmup", "1",
               "--cpu-sample", "0"], env=hook, timeout=1500)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0 and "error" not in d
+    d = _line(r)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["global_batch"] == 1600 and d["config"]["units_per_gpu"] == 200
     assert d["lnl_checksum"] == d["lnl_checksum"] and abs(d["lnl_checksum"]) > 0  # (finite: every unit of every rank evaluated)
