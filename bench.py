@@ -293,7 +293,7 @@ class Workload:
         torch.cuda.empty_cache()
 
 
-def timed_leg(w, steps, warmup, prof_steps, comm, clock=None):
+def timed_leg(w, steps, warmup, prof_steps, comm, clock=None, _retried=False):
     """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks.
     Per-launch HIP events (`roofline`) are recorded during the last `prof_steps` timed steps.  `clock`: optional
     (tensor, stream) -- one wave on its own stream samples the shader clock against the 100 MHz wall clock while
@@ -327,6 +327,13 @@ def timed_leg(w, steps, warmup, prof_steps, comm, clock=None):
     gflops, glaunch, gcalls = C.c_double(), C.c_long(), C.c_long()
     lib.sf_profile_read(ms, C.byref(gflops), C.byref(glaunch), C.byref(gcalls))
     lnl_host, info_host = w.results()
+    if comm.max(float((info_host == -5).any())) > 0 and not _retried:  # (agreed over the ranks: the re-run has barriers)
+        # SF_INFO_INTERNAL: a bounded wait inside the persistent-kernel Cholesky timed out and the launch was aborted (the
+        # kernel needs the GPU to itself: processes sharing a device can starve each other's resident workgroups).  What the
+        # product API does (starfish_amd/_device.py): say so, switch this process to the launch sequences, run again.
+        sys.stderr.write("bench.py: persistent-kernel Cholesky aborted a launch (info = -5): disabled for this process, leg re-run\n")
+        lib.sf_persistent_potrf(0)
+        return timed_leg(w, steps, warmup, prof_steps, comm, clock, _retried=True)
     assert (info_host == 0).all(), info_host
     assert np.isfinite(lnl_host).all()
     clock_mhz = None
@@ -789,6 +796,11 @@ def run(args, in_group, rank, local_rank, world, line):
     # ---- build the model(s) through the product API and pack this rank's parameter rows
     w = Workload(cfg, rank, world, args.scaling, args.grid)
     N, B, n_orders, device, lib = w.N, w.B, w.n_orders, w.device, w.lib
+    if share and world > 1:
+        # test hook only: several ranks on ONE device.  The persistent-kernel Cholesky spins on counters written by its own
+        # other workgroups: it needs them all resident, i.e. the GPU to itself -- one process per GPU, as the metric says.
+        # Eight processes oversubscribing a device deadlock each other's launches (measured: aborted by the 4-s bound).
+        lib.sf_persistent_potrf(0)
     clk = torch.zeros(2, dtype=torch.int64, device=device)
     clk_stream = torch.cuda.Stream(device=device)
     clock = None if os.environ.get("SF_BENCH_NO_CLOCK") else (clk, clk_stream)
@@ -919,6 +931,7 @@ def run(args, in_group, rank, local_rank, world, line):
             },
             "process_group": pg_note,
             "lnl_checksum": lnl_checksum,
+            "persistent_potrf_enabled": bool(lib.sf_persistent_potrf(-1)),
             "whole_path_tflops": t["value"] * w.flops_eval / 1e12,
             "whole_path_frac_of_mfma_peak": t["value"] * w.flops_eval / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
             "roofline": None,  # (filled in below: the flat scalars first -- the driver keeps only the first scalar keys)

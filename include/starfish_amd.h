@@ -332,7 +332,11 @@ int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, const doubl
 
 /* Process-global switch of the persistent-kernel ("dataflow") Cholesky sequence: enable = 0 makes every later factorisation
  * take a launch sequence (kernels without waits inside), 1 restores the default choice, < 0 only queries.  Returns the
- * previous setting.  The recovery path after SF_INFO_INTERNAL. */
+ * previous setting.  The recovery path after SF_INFO_INTERNAL.
+ * The persistent kernel's workgroups wait for each other inside ONE launch: it assumes the process has the device to itself
+ * (one process per GPU).  Several processes oversubscribing one device can keep each other's workgroups from becoming
+ * resident; the waits' 4-s bound then aborts the launch (SF_INFO_INTERNAL for the batch) and the caller falls back -- a
+ * process that knows it shares its device should switch the sequence off up front. */
 int sf_persistent_potrf(int enable);
 
 /* Tuning / test aid (process-global): the batched Cholesky has three launch sequences -- the fused panel kernel

@@ -931,7 +931,13 @@ __device__ __forceinline__ void sf_diag_lds_body(const double* __restrict__ T, i
                                                  int info_off, double* __restrict__ rhs, int ldr,
                                                  double* __restrict__ Cdiag, int ldc, int64_t sC,
                                                  double* __restrict__ Wt, int64_t sW, int fp0, const int b,
-                                                 double* __restrict__ dsm, const int tid) {
+                                                 double* __restrict__ dsm, const int tid, long long* stamps = nullptr) {
+#ifdef SF_TUNING
+#define SF_D_STAMP(i) do { if (stamps && tid == 0) stamps[i] = wall_clock64(); } while (0)
+#else
+#define SF_D_STAMP(i)
+#endif
+    SF_D_STAMP(0);
     // fp0: the first fp0 rows / columns of the tile are virtual (identity in T; Cdiag and rhs point fp0 elements BEFORE
     // the matrix there: never stored, read as zero) -- the first tile of a shifted frame, see sf_potrf_front_pad
     double* Tl = dsm;              // lower blocks (bi >= bj) of the tile at (bi (bi + 1) / 2 + bj) * DBS
@@ -953,10 +959,12 @@ __device__ __forceinline__ void sf_diag_lds_body(const double* __restrict__ T, i
         if (bj <= bi) Tl[tb(bi, bj) + r * DLD + c] = Tb[(int64_t)(16 * bi + r) * SF_LDT + 16 * bj + c];
     }
     __syncthreads();
+    SF_D_STAMP(1);
     int bad = 0;
     const int oF = l15 * DLD + lq;  // operand fragment: row l15, K slice lq of instruction kk stands for k = 4 kk + lq
     for (int k = 0; k < nb; ++k) {
         const int m = nb - 1 - k;
+        if (k == 7) SF_D_STAMP(8);
         // ---- U: wave t <= m holds M(k + t, k), wave t > m the block X(t - m - 1, k) of the inverse
         const int t = wave;
         const bool has = t <= m + k, isM = t <= m;
@@ -979,6 +987,7 @@ __device__ __forceinline__ void sf_diag_lds_body(const double* __restrict__ T, i
             }
         }
         // ---- P: wave 0 factorises the diagonal block and inverts the factor in the accumulator layout
+        if (k == 7) SF_D_STAMP(9);
         if (wave == 0) {
             sf_d4 a0 = acc, f, lt;
 #pragma unroll
@@ -1020,7 +1029,9 @@ __device__ __forceinline__ void sf_diag_lds_body(const double* __restrict__ T, i
                 if (l15 >= row && 16 * k + row >= fp0) Cb[(int64_t)(16 * k + l15) * ldc + 16 * k + row] = lt[r];
             }
         }
+        if (k == 7) SF_D_STAMP(10);
         __syncthreads();
+        if (k == 7) SF_D_STAMP(11);
         // ---- X: the other blocks times F^T, through their own destination block (accumulator -> operand layout)
         if (has && wave != 0) {
 #pragma unroll
@@ -1043,6 +1054,7 @@ __device__ __forceinline__ void sf_diag_lds_body(const double* __restrict__ T, i
         }
         __syncthreads();
     }
+    SF_D_STAMP(2);
     if (tid == 0 && bad && info && info[b] == 0) info[b] = info_off + bad;
     // ---- Wt[c][j] = (L_kk^-1)[c][j] (block (cb, jb) = X(jb, cb)^T, zero above)
     for (int idx = tid; idx < nb * nb * 256; idx += 512) {
@@ -1061,14 +1073,23 @@ __device__ __forceinline__ void sf_diag_lds_body(const double* __restrict__ T, i
             rb[i] = zacc;
         }
     }
+#ifdef SF_TUNING
+    if (stamps) {
+        SF_D_STAMP(3);
+        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SF_D_STAMP(4);
+    }
+#endif
 }
 __global__ __launch_bounds__(512) void k_diag_lds(const double* __restrict__ T, int64_t sT, int pw, int* __restrict__ info,
                                                   int info_off, double* __restrict__ rhs, int ldr,
                                                   double* __restrict__ Cdiag, int ldc, int64_t sC,
-                                                  double* __restrict__ Wt, int64_t sW, int fp0, int prio) {
+                                                  double* __restrict__ Wt, int64_t sW, int fp0, int prio, long long* stamps) {
     extern __shared__ double dsm[];
     if (prio) __builtin_amdgcn_s_setprio(2);
-    sf_diag_lds_body(T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc, sC, Wt, sW, fp0, blockIdx.x, dsm, threadIdx.x);
+    sf_diag_lds_body(T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc, sC, Wt, sW, fp0, blockIdx.x, dsm, threadIdx.x,
+                     blockIdx.x == 0 ? stamps : nullptr);
 }
 static const int chain_prio = SF_TUNE_INT("SF_CHAIN_PRIO", 1);  // tuning aid: 0 = the chain's workgroups at normal wave priority
 #define SF_DIAG_LDS_BYTES ((37 * DBS + 128) * sizeof(double))
@@ -1083,8 +1104,27 @@ static int sf_launch_diag128(double* T, int64_t sT, int pw, int* info, int info_
             SF_HIP(hipFuncSetAttribute((const void*)k_diag_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             return SF_OK;
         }));
+        long long* stamps = nullptr;
+#ifdef SF_TUNING
+        static int printed = 0;
+        static long long* hs = nullptr;
+        if (SF_TUNE_FLAG("SF_DIAG_STAMPS") && printed < 6) {
+            if (!hs) SF_HIP(hipHostMalloc((void**)&hs, 16 * sizeof(long long)));
+            for (int i = 0; i < 16; ++i) hs[i] = 0;
+            stamps = hs;
+        }
+#endif
         hipLaunchKernelGGL(k_diag_lds, dim3(batch), dim3(512), SF_DIAG_LDS_BYTES, s, T, sT, pw, info, info_off, rhs, ldr, Cdiag, ldc,
-                           sC, Wt, sW, fp0, chain_prio);
+                           sC, Wt, sW, fp0, chain_prio, stamps);
+#ifdef SF_TUNING
+        if (stamps) {  // (synchronises) phases of workgroup 0, us
+            (void)hipStreamSynchronize(s);
+            ++printed;
+            fprintf(stderr, "k_diag_lds batch %d: tile load %.1f | 8 block columns %.1f (last column: U %.1f, P %.1f, barrier %.1f, X + barrier %.1f) | W store %.1f + z %.1f | drain %.1f | total %.1f us\n",
+                    batch, (hs[1] - hs[0]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[9] - hs[8]) / 100.0, (hs[10] - hs[9]) / 100.0, (hs[11] - hs[10]) / 100.0,
+                    (hs[2] - hs[11]) / 100.0, 0.0, (hs[3] - hs[2]) / 100.0, (hs[4] - hs[3]) / 100.0, (hs[4] - hs[0]) / 100.0);
+        }
+#endif
     }
     SF_LAUNCH_CHECK();
     return SF_OK;
@@ -1288,7 +1328,8 @@ __device__ __forceinline__ int sf_df_wait_r(const int* f1, int t1, const int* f2
                         break;
                     }
                     const long long waited = wall_clock64() - t0;
-                    if (waited > SF_DF_TIMEOUT_TICKS) {
+                    // (abort_flag[4]: the bound in units of 2^20 ticks when the host asked for another one -- tuning builds)
+                    if (waited > SF_DF_TIMEOUT_TICKS && (abort_flag[4] == 0 || (waited >> 20) > abort_flag[4])) {
                         const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
                         sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3));
                         ok = 0;
@@ -2000,18 +2041,27 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                     for (int nn = 0; nn < 2; ++nn) acc[mi][2 * hf + nn] = (sf_d4){0.0, 0.0, 0.0, 0.0};
-                for (int kk = 0; kk < g.mpad; kk += 4) {
-                    const double* yk = Yb + (int64_t)(kk + lq) * g.ldy;
-                    double ya[TM], yb[2];
+                // (two K steps per round trip: mpad = 8 is one round of loads -- the workgroup has the CU to itself, every
+                // dependent round trip of the prologue is exposed; the MFMA sequence per accumulator is unchanged)
+                for (int kk = 0; kk < g.mpad; kk += 8) {
+                    double ya[2][TM], yb[2][2];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) ya[i] = yk[min(gr + i * 16, g.ldy + g.fp - 1)];
+                    for (int u = 0; u < 2; ++u) {
+                        const double* yk = Yb + (int64_t)(min(kk + 4 * u, g.mpad - 4) + lq) * g.ldy;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) yb[i] = gc + i * 16 >= cfp ? yk[min(gc + i * 16, g.ldy + g.fp - 1)] : 0.0;
+                        for (int i = 0; i < TM; ++i) ya[u][i] = yk[min(gr + i * 16, g.ldy + g.fp - 1)];
 #pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
+                        for (int i = 0; i < 2; ++i) yb[u][i] = gc + i * 16 >= cfp ? yk[min(gc + i * 16, g.ldy + g.fp - 1)] : 0.0;
+                    }
 #pragma unroll
-                        for (int nn = 0; nn < 2; ++nn)
-                            acc[mi][2 * hf + nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[mi], yb[nn], acc[mi][2 * hf + nn], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u) {
+                        if (kk + 4 * u >= g.mpad) break;
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                            for (int nn = 0; nn < 2; ++nn)
+                                acc[mi][2 * hf + nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][mi], yb[u][nn], acc[mi][2 * hf + nn], 0, 0, 0);
+                    }
                 }
             } else {
                 const double* Cin = Cb + (int64_t)row0 * g.lda + k0;
@@ -2093,10 +2143,13 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
     double* Bs = smw + GT * CLD;                // [2][128][GLD] 16-column blocks of W  /  [128][CLD] chunk of L21
     const int lr = tid >> 3, lc = (tid & 7) * 2;  // staging: 128 rows x 8 threads
     // L = T W on the blocks NB, NB + 1 of every wave (NB = 0: panel k, NB = 2: panel k + 1), K blocks in descending order
-    auto solve = [&](const double* Wt, auto nbtag) {
+    // (rw: the K block 7 of W, requested by the caller ahead of the phase that precedes the solve: every global round trip of
+    // the epilogue -- W, L21, z, the diagonal tile -- is in flight before the phase that needs it: with one workgroup per CU
+    // nothing else hides them; 78 -> ~66 us of fixed cost per task, profiles/r05_e_wide_kernel_phases_*.txt)
+    auto w_rows = [&](const double* Wt) { return Wt + (int64_t)b * g.sW + (int64_t)lr * SF_LDT + lc; };
+    auto solve = [&](const double* Wt, double2 rw, auto nbtag) {
         constexpr int NB = decltype(nbtag)::value;
-        const double* Wp = Wt + (int64_t)b * g.sW + (int64_t)lr * SF_LDT + lc;
-        double2 rw = *(const double2*)(Wp + 7 * 16);
+        const double* Wp = w_rows(Wt);
         int buf = 0;
 #pragma unroll
         for (int sbi = 0; sbi < 8; ++sbi) {
@@ -2143,20 +2196,28 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
             buf ^= 1;
         }
     };
+    // ---- requested now, used later: first rows of W_k
+    double2 rw0 = *(const double2*)(w_rows(g.Wt0) + 7 * 16);
     __syncthreads();  // (the main loop's last reads of the ring are done)
     SF_W_STAMP(2);
-    solve(g.Wt0, std::integral_constant<int, 0>());
+    solve(g.Wt0, rw0, std::integral_constant<int, 0>());
     SF_W_STAMP(3);
+    double2 rw1 = *(const double2*)(w_rows(g.Wt1) + 7 * 16);  // (in flight during step 2b)
 
     // 2b: T2 -= L1 L21^T, 32 columns of L1 at a time (chunk q = the blocks of the waves wn == q)
     {
         const double* L21 = Cb + (int64_t)(k0 + GT + lr) * g.lda + k0 + (tid & 7) * 4;
         double* Bc = Bs;  // [128][CLD]
+        auto l21 = [&](int q, double2& l0, double2& l1) {
+            const bool real = (tid & 7) * 4 + q * 32 >= cfp;
+            l0 = real ? *(const double2*)(L21 + q * 32) : make_double2(0.0, 0.0);
+            l1 = real ? *(const double2*)(L21 + q * 32 + 2) : make_double2(0.0, 0.0);
+        };
+        double2 l0, l1, n0 = make_double2(0.0, 0.0), n1 = n0;
+        l21(0, l0, l1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const bool real = (tid & 7) * 4 + q * 32 >= cfp;
-            const double2 l0 = real ? *(const double2*)(L21 + q * 32) : make_double2(0.0, 0.0);
-            const double2 l1 = real ? *(const double2*)(L21 + q * 32 + 2) : make_double2(0.0, 0.0);
+            if (q + 1 < 4) l21(q + 1, n0, n1);  // (the next chunk is in flight under this chunk's MFMAs)
             __syncthreads();  // previous chunk consumed
             if (wn == q) {
 #pragma unroll
@@ -2192,11 +2253,52 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
                             acc[mi][2 + nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], bb[nn], acc[mi][2 + nn], 0, 0, 1);  // neg
                 }
             }
+            l0 = n0;
+            l1 = n1;
         }
     }
     SF_W_STAMP(4);
-    solve(g.Wt1, std::integral_constant<int, 2>());
+    solve(g.Wt1, rw1, std::integral_constant<int, 2>());
     SF_W_STAMP(5);
+    // ---- the slab's diagonal tile (step 4) is requested before the stores of step 3
+    constexpr int TLD = 130;
+    const int nsb = wn == 0 ? 3 : 2;
+    int sbi[3], sbj[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int t = min(wm + 4 * (wn + 4 * j), 35);
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        sbi[j] = bi;
+        sbj[j] = t - bi * (bi + 1) / 2;
+    }
+    sf_d4 acc2[3];
+    {
+        const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
+        if (rows_here == GT) {  // (full slab: straight-line loads -- see k_chol_panel, step 4)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
+                    acc2[j][r] = Sin[(int64_t)row * g.lda + col];  // (a wave with two blocks reads a third one it never stores)
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
+                    acc2[j][r] = (j < nsb && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
+                }
+        }
+    }
+    double zc[TN] = {0.0, 0.0, 0.0, 0.0};
+    if (RHS && g.rhs) {
+        const double* z = g.rhs + (int64_t)b * g.ldr + k0;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) zc[ni] = WBC(ni) + l15 >= cfp ? z[WBC(ni) + l15] : 0.0;
+    }
 
     // ---------------------------------------------------------------- 3: L in place, rhs -= L z
     {
@@ -2213,10 +2315,6 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
                 }
             }
         if (RHS && g.rhs) {
-            const double* z = g.rhs + (int64_t)b * g.ldr + k0;
-            double zc[TN];
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) zc[ni] = WBC(ni) + l15 >= cfp ? z[WBC(ni) + l15] : 0.0;
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -2241,39 +2339,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
     // lower-triangular enumeration) and accumulate over both panels in registers -- four barriers, no K-slab staging loop,
     // no cross-wave reduction.
     {
-        constexpr int TLD = 130;
         double* Ts = smw;
-        const int nsb = wn == 0 ? 3 : 2;
-        int sbi[3], sbj[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int t = min(wm + 4 * (wn + 4 * j), 35);
-            int bi = 0;
-            while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-            sbi[j] = bi;
-            sbj[j] = t - bi * (bi + 1) / 2;
-        }
-        sf_d4 acc2[3];
-        {
-            const double* Sin = Cb + (int64_t)row0 * g.lda + row0;
-            if (rows_here == GT) {  // (full slab: straight-line loads -- see k_chol_panel, step 4)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
-                        acc2[j][r] = Sin[(int64_t)row * g.lda + col];  // (a wave with two blocks reads a third one it never stores)
-                    }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * sbi[j] + lq + 4 * r, col = 16 * sbj[j] + l15;
-                        acc2[j][r] = (j < nsb && row < rows_here && col < rows_here) ? Sin[(int64_t)row * g.lda + col] : 0.0;
-                    }
-            }
-        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             __syncthreads();  // the previous contents of the LDS image are dead
@@ -3457,7 +3523,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                             // (s_ints[5]: the 10.5 ms unit of the wall clock at which this idle spell began, + 1; 0 = none)
                             const int now = (int)((wall_clock64() >> 20) & 0x3fffffff) + 1;
                             if (s_ints[5] == 0) s_ints[5] = now;
-                            if (((now - s_ints[5]) & 0x3fffffff) > (int)(SF_DF_TIMEOUT_TICKS >> 20)) {
+                            if (((now - s_ints[5]) & 0x3fffffff) > (a.abort_flag[4] ? a.abort_flag[4] : (int)(SF_DF_TIMEOUT_TICKS >> 20))) {
                                 sf_df_report(a.abort_flag, a.chain_next, nt);
                                 t = -1;
                             }
@@ -3858,6 +3924,8 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     // test aids: a launch that finds its abort flag raised (every matrix comes back SF_INFO_INTERNAL: the callers' recovery
     // path); a dispenser that leaves every chain / front task to the rescue of the waits (sf_df_wait_r)
     if (SF_TUNE_FLAG("SF_DF_FORCE_ABORT")) SF_HIP(hipMemsetAsync(a.abort_flag, 1, 1, s));
+    static const int timeout_s = SF_TUNE_INT("SF_DF_TIMEOUT_S", 0);  // (bound of the waits in seconds instead of 4)
+    if (timeout_s > 0) SF_HIP(hipMemsetD32Async((hipDeviceptr_t)(a.abort_flag + 4), timeout_s * 95, 1, s));
     a.miss_claims = SF_TUNE_INT("SF_DF_MISS_CLAIMS", 0);
 #endif
 

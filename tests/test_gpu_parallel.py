@@ -19,6 +19,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _ranks_share_one_gpu():
+    """The ranks of these tests are processes on ONE device (the test box has one GPU).  The persistent-kernel Cholesky spins
+    on counters written by its own other workgroups and needs them all resident -- the GPU to itself, one process per GPU as
+    in production; processes oversubscribing a device can starve each other's launches until the 4-s bound aborts them
+    (measured with eight bench ranks, profiles/r05_g_shared_gpu_abort.txt; the product then warns and falls back, see
+    tests/test_gpu_recovery.py).  Not what these tests are about: switched off up front."""
+    from starfish_amd import _lib
+
+    _lib.require_gpu().sf_persistent_potrf(0)
+
+
 def _worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
@@ -30,6 +41,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)  # host gather only: any backend does
     try:
         torch.cuda.set_device(0)
+        _ranks_share_one_gpu()
         # single order: every rank evaluates its contiguous slice of the walkers
         o = synth.make_order(N=512, m=4, seed=21)
         model = synth.build_model(o)
@@ -100,6 +112,7 @@ def _cfg4_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
+        _ranks_share_one_gpu()
         g = load_golden("model_cfg3.npz")
         n_orders, N, P = int(g["n_orders"][0]), int(g["N"][0]), g["P"]
         B = len(P)
