@@ -954,9 +954,30 @@ __device__ __forceinline__ void sf_diag_lds_body(const double* __restrict__ T, i
     auto tb = [](int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * DBS; };
     auto eb = [](int e, int j) { return (j * (j + 1) / 2 + e) * DBS; };  // = tb(j, e)
 
-    for (int idx = tid; idx < nb * nb * 256; idx += 512) {
-        const int blk = idx >> 8, bi = blk / nb, bj = blk - bi * nb, r = (idx >> 4) & 15, c = idx & 15;
-        if (bj <= bi) Tl[tb(bi, bj) + r * DLD + c] = Tb[(int64_t)(16 * bi + r) * SF_LDT + 16 * bj + c];
+    {
+        // the lower blocks only, 16 bytes per load, ALL of a thread's loads in flight before the first LDS store (nine per
+        // thread for a full tile: one round trip instead of thirty-two short ones; 5.5 -> ~3 us of the tile's 41)
+        const int cnt = nb * (nb + 1) / 2 * 128;
+        double2 v[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int e = min(tid + 512 * u, cnt - 1);
+            const int blk = e >> 7, r = (e >> 3) & 15, c2 = e & 7;
+            int bi = 0;
+            while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+            const int bj = blk - bi * (bi + 1) / 2;
+            v[u] = *(const double2*)(Tb + (int64_t)(16 * bi + r) * SF_LDT + 16 * bj + 2 * c2);
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int e = tid + 512 * u;
+            if (e < cnt) {
+                const int r = (e >> 3) & 15, c2 = e & 7;
+                double* d = Tl + (e >> 7) * DBS + r * DLD + 2 * c2;  // (tb(bi, bj) = blk * DBS: the same enumeration)
+                d[0] = v[u].x;
+                d[1] = v[u].y;
+            }
+        }
     }
     __syncthreads();
     SF_D_STAMP(1);
@@ -1057,20 +1078,26 @@ __device__ __forceinline__ void sf_diag_lds_body(const double* __restrict__ T, i
     SF_D_STAMP(2);
     if (tid == 0 && bad && info && info[b] == 0) info[b] = info_off + bad;
     // ---- Wt[c][j] = (L_kk^-1)[c][j] (block (cb, jb) = X(jb, cb)^T, zero above)
-    for (int idx = tid; idx < nb * nb * 256; idx += 512) {
-        const int blk = idx >> 8, bi = blk / nb, bj = blk - bi * nb, r = (idx >> 4) & 15, c = idx & 15;
-        Wb[(int64_t)(16 * bi + r) * SF_LDT + 16 * bj + c] = bj <= bi ? El[eb(bj, bi) + c * DLD + r] : 0.0;
+    for (int idx = tid; idx < nb * nb * 128; idx += 512) {  // (16-byte stores: half as many store instructions per thread)
+        const int blk = idx >> 7, bi = blk / nb, bj = blk - bi * nb, r = (idx >> 3) & 15, c = (idx & 7) * 2;
+        const double* e = El + eb(bj, bi) + c * DLD + r;
+        *(double2*)(Wb + (int64_t)(16 * bi + r) * SF_LDT + 16 * bj + c) = bj <= bi ? make_double2(e[0], e[DLD]) : make_double2(0.0, 0.0);
     }
     // ---- z_k = L_kk^-1 r_k with the explicit inverse
     if (rhs) {
         double* rb = rhs + (int64_t)b * ldr;
         if (tid < pw) rz[tid] = tid >= fp0 ? rb[tid] : 0.0;
         __syncthreads();
-        if (tid < pw && tid >= fp0) {
-            const int i = tid, ibk = i >> 4, ir = i & 15;
+        {
+            // four lanes per row (j = p, p + 4, ... <= i each), added by two shuffles: the 128-term chain of one lane per row
+            // was 3.9 us of the tile's 41
+            const int i = tid >> 2, p = tid & 3, ibk = i >> 4, ir = i & 15;
             double zacc = 0.0;
-            for (int j = 0; j <= i; ++j) zacc = __builtin_fma(El[eb(j >> 4, ibk) + (j & 15) * DLD + ir], rz[j], zacc);
-            rb[i] = zacc;
+            if (i < pw)
+                for (int j = p; j <= i; j += 4) zacc = __builtin_fma(El[eb(j >> 4, ibk) + (j & 15) * DLD + ir], rz[j], zacc);
+            zacc += __shfl_xor(zacc, 1);
+            zacc += __shfl_xor(zacc, 2);
+            if (p == 0 && i < pw && i >= fp0) rb[i] = zacc;
         }
     }
 #ifdef SF_TUNING
@@ -1964,12 +1991,10 @@ struct sf_panelw_args {
 #endif
 
 template <bool RHS>
-__global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
+__device__ __forceinline__ void sf_panelw_body(const sf_panelw_args& g, const int id, double* __restrict__ smw, const int tid) {
     constexpr int TM = 2, TN = 4;
-    extern __shared__ __attribute__((aligned(16))) double smw[];
     double* red = smw + 3 * WST;  // [4][GT]
 
-    const int id = sf_xcd_remap(blockIdx.x, gridDim.x);
     const int b = id / g.nslab;
     const int sl = id - b * g.nslab;
     const int row0 = g.row0 + sl * g.slab_step * GT;
@@ -1977,7 +2002,6 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
     const int k0 = g.k0;
     const int cfp = k0 == 0 ? g.fp : 0;  // pair columns below cfp are virtual (zero below the diagonal tile)
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the four waves of a SIMD (w, w + 4, w + 8, w + 12) share a row group and take the four column groups: the
@@ -2405,6 +2429,13 @@ __global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
     }
 #endif
 #undef WBC
+}
+template <bool RHS>
+__global__ __launch_bounds__(1024) void k_chol_panel_w(sf_panelw_args g) {
+    extern __shared__ __attribute__((aligned(16))) double smw[];
+    // (several tasks per workgroup -- the 5-15 us a CU needs to start a 16-wave workgroup with 148 KB of LDS amortised -- measured
+    // without any gain at cfg 2 and cfg 3: profiles/r05_h_wide_tasks_per_workgroup_ab.txt)
+    sf_panelw_body<RHS>(g, sf_xcd_remap(blockIdx.x, gridDim.x), smw, threadIdx.x);
 }
 
 // The per-matrix scratch strides are skewed by a few hundred bytes: with strides that are multiples of
