@@ -379,6 +379,47 @@ def code_id():
     return h.hexdigest()[:16]
 
 
+def fill_unaligned_leg(npix=3000, batch=128, steps=5, warmup=2):
+    """The same write-only fill on cfg 3's order size, N = 3000 with row stride N: every other row starts 64 bytes into a
+    128-byte line.  Reported next to the row-padded variant (ld = 3008: what a caller that may choose its stride should do)."""
+    import torch
+
+    from starfish_amd import _device as D
+    from starfish_amd import synth
+
+    order = synth.make_order(N=npix)
+    model = synth.build_model(order)
+    dev, md, rows = model._pack(synth.walker_ball(order, B=batch, seed=1), update_caches=False)
+    lib = dev.lib
+    P_dev = D.to_dev(rows, dev.dev)
+    info = D.empty((batch,), dev.dev, torch.int32)
+    out = {}
+    for ld in (npix, -(-npix // 16) * 16):
+        cov = torch.empty((batch * npix * ld,), dtype=torch.float64, device=dev.dev)
+        for _ in range(warmup):
+            dev.cov_fill_device(md, P_dev, cov, ld, npix * ld, lower_only=False, add_jitter=True, info=info)
+        torch.cuda.synchronize()
+        lib.sf_profile_read(None, None, None, None)
+        lib.sf_profile_enable(1)
+        for _ in range(steps):
+            dev.cov_fill_device(md, P_dev, cov, ld, npix * ld, lower_only=False, add_jitter=True, info=info)
+        torch.cuda.synchronize()
+        lib.sf_profile_enable(0)
+        ms = (C.c_double * 6)()
+        lib.sf_profile_read(ms, None, None, None)
+        assert (info.cpu().numpy() == 0).all()
+        nbytes = 8.0 * npix * npix * batch
+        gbs = nbytes / (ms[1] / steps * 1e-3) / 1e9
+        out["ld_n" if ld == npix else "ld_padded"] = {"ld": ld, "avg_launch_ms": ms[1] / steps, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+        del cov
+        torch.cuda.empty_cache()
+    dev.release_workspace()
+    return {"N": npix, "batch": batch, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": out["ld_n"]["achieved"], "frac": out["ld_n"]["frac"], "ld_n": out["ld_n"], "ld_padded": out["ld_padded"],
+            "note": "sf_cov_fill_batch, full dense C of N = 3000 rows: row stride N (rows alternate between 0 and 64 bytes into a "
+            "128-byte line) and row stride 3008 (every row line-aligned); algorithmic bytes 8 N^2 B"}
+
+
 def fill_leg(w, steps=5, warmup=2):
     """the fill stage alone is HBM-WRITE bound.  sf_cov_fill_batch, full dense matrices (both triangles,
     sigma^2 + K_global + K_local + rank-m term on MFMA + jitter), row stride N: 8 N^2 B algorithmic bytes per launch, all
@@ -853,6 +894,7 @@ def run(args, in_group, rank, local_rank, world, line):
         base_ms_per_eval = t["ms_per_step"] / w.n_local
         fill = fill_leg(w)
         w.release()
+        fill["unaligned"] = fill_unaligned_leg()
         # strong-scaling proxy on the one GPU: the per-rank batch of 2 / 4 / 8 ranks (128/G walkers)
         proxy = [{"ranks_equivalent": 1, "batch": B, "value": t["value"], "ms_per_step": t["ms_per_step"],
                   "per_eval_efficiency_vs_full_batch": 1.0}]
