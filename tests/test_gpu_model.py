@@ -496,3 +496,32 @@ def test_paper_form_of_the_emulator_covariance_is_a_non_default_switch():
         p = dict(synth.vector_to_oracle_params(P[b]))
         assert close_lnl(lc[b], O.log_likelihood(oo, p))
         assert close_lnl(lp[b], O.log_likelihood(oo, dict(p, emulator_cov="paper")))
+
+
+@pytest.mark.parametrize("N,ld,m,structured", [(3000, 3000, 8, True), (3000, 3000, 8, False), (1000, 1000, 4, False),
+                                               (1001, 1016, 12, True), (1001, 1016, 16, False), (2000, 2008, 8, True)])
+def test_dense_fill_on_rows_that_alternate_between_two_line_phases(N, ld, m, structured):
+    """Row stride = 8 mod 16 doubles (cfg 3's N = 3000 with ld = N): every other row starts 64 bytes into a 128-byte line and
+    sf_cov_fill_batch takes the kernel whose shifted rows use a column window 8 further right (k_fill_dense_shift: quad-permuted
+    B fragments, head / tail blocks against structured, diagonal and edge tiles).  Same MFMA sequence per element: the matrix
+    must equal the line-aligned layout's (ld a multiple of 16: the unshifted kernels) BIT FOR BIT -- three matrices, so that with
+    an odd number of rows the phase also flips from matrix to matrix -- and nothing may land in the padding columns or behind
+    the last matrix."""
+    o = synth.make_order(N=N, m=m, seed=9)
+    do = device_order(oracle_order(o))
+    plist = [synth.vector_to_oracle_params(p) for p in synth.walker_ball(o, B=3, seed=4)]
+    if not structured:
+        plist = [{k: v for k, v in p.items() if k not in ("global_cov", "local_cov")} for p in plist]
+    md, rows = pack_rows(do, plist)
+    ref, info = do.cov_fill(md, rows, ld=-(-N // 16) * 16 + 16, add_jitter=True)
+    assert (info == 0).all()
+    got, info, guard = do.cov_fill(md, rows, ld=ld, add_jitter=True, guard=4096)
+    assert (info == 0).all() and got.shape == (3, N, ld)
+    assert (guard == -7.0).all()
+    for b in range(3):
+        np.testing.assert_array_equal(got[b][:, :N], ref[b][:, :N])
+        np.testing.assert_array_equal(got[b][:, :N], got[b][:, :N].T)
+        assert not got[b][:, N:].any()
+    f_or, c_or, _ = O.forward_model(oracle_order(o), plist[1])
+    c_or[np.diag_indices(N)] += 1e-10
+    np.testing.assert_allclose(got[1][:, :N], c_or, rtol=1e-10, atol=1e-11 * np.abs(c_or).max())
