@@ -648,127 +648,6 @@ __global__ __launch_bounds__(256, 4) void k_fill_dense_plain(sf_fill_args a, int
     }
 }
 
-// The same for matrices whose rows alternate between 0 and 64 bytes into a 128-byte line (row stride = 8 mod 16 doubles: N =
-// 3000 with ld = N): with every row taking the same 16-column blocks each 128-byte segment a wave instruction writes straddles
-// two lines on every other row (4.5 instead of 5.5 TB/s on the rank-m part, profiles/r05_d_fill_alignment_*).  Here a wave's
-// two row blocks hold the rows of ONE line phase each (rows R0 + 2 g + i: block i) and the block of the rows that start 64 bytes
-// into a line takes its columns 8 further right, so that every store is line-aligned again.  Its B fragments are the
-// neighbour lanes' (column c + 8 of a 16-column block = lane g ^ 2 of the same block or of the next one): one quad permute, no
-// extra loads but the one block to the right of the wave's columns.  A shifted row owns the columns [C0 + 8, C0 + 72) of a
-// PLAIN tile (no structured kernel, not on the diagonal, inside the matrix); against a tile of any other kind -- written
-// unshifted, by its own path -- the window is cut at C0 + 64, and the first 8 columns behind such a tile (or of the row) are a
-// head block of the plain tile.  Same MFMA sequence per element: same bits as the unshifted kernels.
-template <int KK, int SPAN>
-__global__ __launch_bounds__(256, 4) void k_fill_dense_shift(sf_fill_args a, int nt, const unsigned char* __restrict__ smap) {
-    const int nch = (nt + SPAN - 1) / SPAN;
-    const int id = sf_xcd_remap_f(blockIdx.x, gridDim.x);
-    const int b = id / (nt * nch);
-    const int r = id - b * nt * nch;
-    const int tm = r / nch, ch = r - tm * nch;
-    const int t0 = ch * SPAN, cnt = min(SPAN, nt - t0);
-    const unsigned char* __restrict__ row = smap ? smap + ((int64_t)b * nt + tm) * nt : nullptr;
-
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int gam = lane & 15, q = lane >> 4;
-    const int n = a.n;  // (caller matrices: the stored extent is n)
-    const int R0 = tm * FT + (w >> 1) * 32;
-    if (R0 >= n) return;
-    const double* __restrict__ Yb = a.Y + (int64_t)b * a.mpad * a.ldy;
-    double* __restrict__ Cb = a.C + (int64_t)b * a.stride;
-    const int colperm = 4 * (gam & 3) + (gam >> 2);
-    // line phase of the rows: row R0 + 2 g + i starts (p0 + i) & 1 half lines into a line (R0 even, ld = 8 mod 16)
-    const int p0 = (int)((((uintptr_t)(Cb + (int64_t)R0 * a.lda)) >> 6) & 1);
-    // support-map bytes of the segment and of its two neighbours: one round trip, one ballot
-    unsigned char fb = 0;
-    if (row && lane < cnt + 2 && t0 - 1 + lane >= 0 && t0 - 1 + lane < nt) fb = row[t0 - 1 + lane];
-    const unsigned long long smask = __ballot(fb != 0);
-    auto structured = [&](int tn) { return ((smask >> (tn - t0 + 1)) & 1) != 0; };
-    auto plain = [&](int tn) {  // a tile the shifted rows may treat as theirs
-        return tn >= 0 && tn < nt && tn != tm && (tn + 1) * FT <= n && (tm + 1) * FT <= n && !structured(tn);
-    };
-    // rows of block i: R0 + 2 g + i (clamped loads: Y holds npad >= 64 nt columns per row)
-    double brow[KK][2];
-#pragma unroll
-    for (int k = 0; k < KK; ++k)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) brow[k][i] = Yb[(int64_t)(4 * k + q) * a.ldy + R0 + 2 * gam + i];
-    const int i0 = tm % cnt;
-    double acol[SPAN][KK][3];  // blocks j = 0, 1 of the wave's 32 columns and the block to their right
-#pragma unroll
-    for (int t = 0; t < SPAN; ++t) {
-        const int tn = t0 + (i0 + t < cnt ? i0 + t : i0 + t - cnt);
-        const int C0 = (t < cnt ? tn : t0) * FT + (w & 1) * 32;
-#pragma unroll
-        for (int k = 0; k < KK; ++k)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acol[t][k][j] = Yb[(int64_t)(4 * k + q) * a.ldy + min(C0 + j * 16 + colperm, a.ldy - 1)];
-    }
-#pragma unroll
-    for (int t = 0; t < SPAN; ++t) {
-        const int tn = t0 + (i0 + t < cnt ? i0 + t : i0 + t - cnt);
-        if (t >= cnt || structured(tn) || tn * FT >= n) continue;  // (structured tiles: k_fill_dense_band)
-        const int C0 = tn * FT + (w & 1) * 32;
-        if (!plain(tn)) {
-            // diagonal / edge tile: the unshifted body.  Its rows are those of the unshifted layout: fragments reloaded.
-            sf_d4 acc[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = (sf_d4){0.0, 0.0, 0.0, 0.0};
-            if (C0 < n) {
-#pragma unroll
-                for (int k = 0; k < KK; ++k) {
-                    double br[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) br[i] = Yb[(int64_t)(4 * k + q) * a.ldy + R0 + i * 16 + gam];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[t][k][j], br[i], acc[i][j], 0, 0, 0);
-                }
-                sf_tile_finish<false>(a, b, R0, C0, acc);
-            }
-            continue;
-        }
-        const bool tail_ok = plain(tn + 1), head = !plain(tn - 1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool sh = ((p0 + i) & 1) != 0;  // rows of this block start 64 bytes into a line: columns + 8
-            sf_d4 acc[2] = {(sf_d4){0.0, 0.0, 0.0, 0.0}, (sf_d4){0.0, 0.0, 0.0, 0.0}};
-#pragma unroll
-            for (int k = 0; k < KK; ++k)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // column c + 8 of block j: lane g ^ 2 of block j (g & 2 clear) or of block j + 1 (set)
-                    const double give = (gam & 2) ? acol[t][k][j] : acol[t][k][j + 1];
-                    const double ac = sh ? __shfl_xor(give, 2) : acol[t][k][j];
-                    acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac, brow[k][i], acc[j], 0, 0, 0);
-                }
-            const int rw = R0 + 2 * gam + i;
-            double* drow = Cb + (int64_t)rw * a.lda;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c0 = C0 + (sh ? 8 : 0) + j * 16 + 4 * q;
-                // (the last 8 columns of a shifted window lie in the next tile: written here only if that tile is plain too)
-                if (!sh || c0 < tn * FT + FT || tail_ok) {
-                    *(double2*)(drow + c0) = make_double2(acc[j][0], acc[j][1]);
-                    *(double2*)(drow + c0 + 2) = make_double2(acc[j][2], acc[j][3]);
-                }
-            }
-            if (sh && head && (w & 1) == 0) {  // the 8 columns in front of the shifted window that no plain tile to the left covers
-                sf_d4 hd = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int k = 0; k < KK; ++k) hd = __builtin_amdgcn_mfma_f64_16x16x4f64(acol[t][k][0], brow[k][i], hd, 0, 0, 0);
-                if (q < 2) {
-                    *(double2*)(drow + C0 + 4 * q) = make_double2(hd[0], hd[1]);
-                    *(double2*)(drow + C0 + 4 * q + 2) = make_double2(hd[2], hd[3]);
-                }
-            }
-        }
-    }
-}
-
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void k_fill_dense_band(sf_fill_args a, int nt, int G,
                                                               const unsigned short* __restrict__ list,
@@ -864,19 +743,6 @@ int sf_launch_fill_dense(const sf_fill_args& a, int B, unsigned char* smap, unsi
         sf_set_error("fill grid too large");
         return SF_EINVAL;
     }
-    // rows alternating between two line phases (row stride = 8 mod 16 doubles, matrices and base a multiple of 64 bytes)
-    static const int no_shift = SF_TUNE_INT("SF_FILL_NO_SHIFT", 0);
-    const bool shifted = !no_shift && (a.lda & 15) == 8 && (a.stride & 7) == 0 && (((uintptr_t)a.C) & 63) == 0 && nout == a.n;
-    if (shifted) {
-        const long long nblk2 = (long long)nt * ((nt + 1) / 2) * B;
-        switch (KK) {
-            case 1: hipLaunchKernelGGL((k_fill_dense_shift<1, 2>), dim3((unsigned)nblk2), dim3(256), 0, s, a2, nt, pm); break;
-            case 2: hipLaunchKernelGGL((k_fill_dense_shift<2, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a2, nt, pm); break;
-            // (three fragments per column block: larger ranks take two tiles per workgroup to stay inside 128 VGPRs)
-            case 3: hipLaunchKernelGGL((k_fill_dense_shift<3, 2>), dim3((unsigned)nblk2), dim3(256), 0, s, a2, nt, pm); break;
-            default: hipLaunchKernelGGL((k_fill_dense_shift<4, 2>), dim3((unsigned)nblk2), dim3(256), 0, s, a2, nt, pm); break;
-        }
-    } else
     switch (KK) {
         case 1:
             if (span == 8) hipLaunchKernelGGL((k_fill_dense_plain<1, 8>), dim3((unsigned)nblk), dim3(256), 0, s, a2, nt, pm);

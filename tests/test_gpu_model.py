@@ -501,12 +501,12 @@ def test_paper_form_of_the_emulator_covariance_is_a_non_default_switch():
 @pytest.mark.parametrize("N,ld,m,structured", [(3000, 3000, 8, True), (3000, 3000, 8, False), (1000, 1000, 4, False),
                                                (1001, 1016, 12, True), (1001, 1016, 16, False), (2000, 2008, 8, True)])
 def test_dense_fill_on_rows_that_alternate_between_two_line_phases(N, ld, m, structured):
-    """Row stride = 8 mod 16 doubles (cfg 3's N = 3000 with ld = N): every other row starts 64 bytes into a 128-byte line and
-    sf_cov_fill_batch takes the kernel whose shifted rows use a column window 8 further right (k_fill_dense_shift: quad-permuted
-    B fragments, head / tail blocks against structured, diagonal and edge tiles).  Same MFMA sequence per element: the matrix
-    must equal the line-aligned layout's (ld a multiple of 16: the unshifted kernels) BIT FOR BIT -- three matrices, so that with
-    an odd number of rows the phase also flips from matrix to matrix -- and nothing may land in the padding columns or behind
-    the last matrix."""
+    """Row stride = 8 mod 16 doubles (cfg 3's N = 3000 with ld = N): every other row starts 64 bytes into a 128-byte line.  The
+    matrix must equal the line-aligned layout's (ld a multiple of 16) BIT FOR BIT -- three matrices, so that with an odd number
+    of rows the phase also flips from matrix to matrix; ranks m = 4 ... 16 (one to four MFMA K steps), with and without
+    structured kernels -- and nothing may land in the padding columns or behind the last matrix.  (Written for a kernel with a
+    per-row-parity column window, profiles/r05_l_fill_shifted_rows_ab.txt: measured, not kept; the layout property stays
+    tested.)"""
     o = synth.make_order(N=N, m=m, seed=9)
     do = device_order(oracle_order(o))
     plist = [synth.vector_to_oracle_params(p) for p in synth.walker_ball(o, B=3, seed=4)]
