@@ -553,7 +553,9 @@ __global__ __launch_bounds__(256) void k_dense_map(sf_fill_args a, int nt, unsig
     if (e >= nt * nt) return;
     const int tm = e / nt, tn = e - tm * nt;
     const double* __restrict__ P = a.params + (int64_t)b * a.pstride;
-    const int rlo = tm * FT, clo = tn * FT;
+    // (the flag of a tile is evaluated on the tile BELOW the diagonal of the pair {(tm, tn), (tn, tm)}: the map is symmetric by
+    // construction, which the mirror writes of k_fill_dense_band and the skips of k_fill_dense_plain rely on)
+    const int rlo = max(tm, tn) * FT, clo = min(tm, tn) * FT;
     bool g = false;
     unsigned lm = 0;
     if (rlo < a.n && clo < a.n) {

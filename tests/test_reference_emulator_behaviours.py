@@ -100,9 +100,13 @@ def test_emulator_hyper_parameters_and_persistence(tmp_path):
 
 
 def test_v11_follows_every_way_of_changing_the_hyper_parameters():
-    """One matrix for every consumer (the reference uses self.v11 for queries and likelihood alike, emulator.py:126-128,
-    569-571, 612): the property setters and direct edits of ``hyperparams`` invalidate the cached host matrix (and with
-    it the query context / factor), not only set_param_dict."""
+    """A DELIBERATE DIVERGENCE from the reference (deviation ix), not its behaviour: there ``v11`` changes only
+    in ``__init__`` and ``set_param_dict`` / ``set_param_vector`` (emulator.py:126-128, 569-571) while the property setters
+    ``lambda_xi`` / ``variances`` / ``lengthscales`` (emulator.py:142-183) and direct edits of ``hyperparams`` leave the OLD matrix
+    in place for later queries.  Here one matrix serves every consumer (host attribute, query context, model contexts, the
+    device-built matrix of log_likelihood) and it always describes the current hyper-parameters: every way of changing them
+    invalidates the cached host matrix and with it the query context / factor.  The documented workflow (train ->
+    set_param_vector -> queries) is identical in both."""
     emu = make_emulator()
 
     def expect():
