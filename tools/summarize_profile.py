@@ -73,6 +73,16 @@ for d in sorted(os.listdir(src)):
                 dur[k] += t
             if d.startswith("SQ_VALU_MFMA"):
                 sqdur[k] += t
+# shader clock for the pipe-busy fraction: what the plain bench run of the same script measured (boxes hold 2.1 - 2.4 GHz)
+clock_hz = 2.25e9
+try:
+    with open(os.path.join(src, "bench_plain.json")) as fh:
+        line = [ln for ln in fh if ln.startswith("{")][-1]
+    mhz = (json.loads(line).get("roofline") or {}).get("sustained_clock_mhz")
+    if mhz and 1000 < mhz < 3000:
+        clock_hz = mhz * 1e6
+except Exception:
+    pass
 summary = {}
 for k, v in agg.items():
     e = {"launches_per_step": calls[k] / PMC_STEPS, "ms_per_step_under_pmc": round(dur[k] / PMC_STEPS, 3)}
@@ -83,8 +93,8 @@ for k, v in agg.items():
     if "TCC_HIT_sum" in v:
         e["l2_hit_rate"] = round(v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 3)
     if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and sqdur[k] > 0:
-        # busy cycles summed over the 1024 SIMDs / (SIMDs x kernel time x 2.25 GHz sustained clock)
-        e["mfma_pipe_busy_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * sqdur[k] * 1e-3 * 2.25e9), 3)
+        # busy cycles summed over the 1024 SIMDs / (SIMDs x kernel time x the sustained clock of the plain run)
+        e["mfma_pipe_busy_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * sqdur[k] * 1e-3 * clock_hz), 3)
     if "fetch_GB_per_step_corrected_x2" in e or "write_GB_per_step" in e:
         e["hbm_bytes_per_launch"] = (e.get("fetch_GB_per_step_corrected_x2", 0) + e.get("write_GB_per_step", 0)) * 1e9 / max(1.0, e["launches_per_step"])
     summary[k] = e
@@ -105,6 +115,7 @@ try:  # the id of the code the counters were collected on (bench.py reports the 
     import bench
 
     summary["_code_id"] = bench.code_id()
+    summary["_clock_mhz_for_pipe_busy"] = round(clock_hz / 1e6, 1)
 except Exception as e:  # pragma: no cover
     summary["_code_id"] = None
 json.dump(summary, open(dst + "_pmc_summary.json", "w"), indent=1, sort_keys=True)
