@@ -2123,32 +2123,46 @@ __device__ __forceinline__ void sf_panelw_body(const sf_panelw_args& g, const in
 #pragma unroll
             for (int i = 0; i < TN; ++i) bb[i] = *(const double2*)(S + brow + ((i >> 1) * GT + (i & 1) * 16) * GK);
         };
-        auto mfma16 = [&](const double2(&a)[TM], const double2(&bb)[TN]) {
+        // (instructions lo .. hi - 1 of a 16-MFMA burst, in the order  x: (mi, ni) ...,  y: (mi, ni) ...)
+        auto mfma_part = [&](const double2(&a)[TM], const double2(&bb)[TN], auto lo_t, auto hi_t) {
+            constexpr int lo = decltype(lo_t)::value, hi = decltype(hi_t)::value;
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi].x, bb[ni].x, acc[mi][ni], 0, 0, 1);  // neg:[1,0,0]
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi].y, bb[ni].y, acc[mi][ni], 0, 0, 1);
-                }
+            for (int i = lo; i < hi; ++i) {
+                const int y = i >> 3, mi = (i >> 2) & 1, ni = i & 3;
+                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(y ? a[mi].y : a[mi].x, y ? bb[ni].y : bb[ni].x, acc[mi][ni], 0, 0, 1);  // neg:[1,0,0]
+            }
         };
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 8> I8;
+        typedef std::integral_constant<int, 16> I16;
         double2 a0[TM], b0[TN], a1[TM], b1[TN];
         int s0 = 0, s1 = 1, s2 = 2;  // stages of slab kt, kt + 1, kt + 2
         if (nk > 0 && wave_live) frag(0, 0, a0, b0);
         for (int kt = 0; kt < nk; ++kt) {
+            // Order of a slab: the first eight MFMAs (their fragments were read before the barrier) go out BEFORE the slab's
+            // loads and fragment reads.  All sixteen waves leave the barrier in step; whatever stands between it and a wave's first
+            // MFMA -- three loads with their M0 moves, six LDS reads -- is time in which no wave of the CU feeds the matrix
+            // pipes (one workgroup per CU: nobody else does).  Same box, potrf of cfg 2 (ms): loads first 47.1, after 4 / 8 / 12
+            // MFMAs 46.7 / 46.5 / 46.55; loads after all sixteen 52.0 (then they no longer land within the slab);
+            // profiles/r05_p_wide_k_loop_issue_order_ab.txt.  (s_setprio is a scheduling boundary for hipcc: the order holds.
+            // The bursts run at raised priority: a wave with matrix work ready goes before the waves that are still issuing their
+            // fragment reads -- cfg 2 48.77 -> 48.53 ms on the same box, three runs each.)
+            if (wave_live) {
+                __builtin_amdgcn_s_setprio(1);
+                mfma_part(a0, b0, I0(), I8());
+                __builtin_amdgcn_s_setprio(0);
+            }
 #ifndef SF_EXPW_NOGLOAD
             if (kt + 2 < nk) gload(kt + 2, s2);
 #endif
             if (wave_live) {
-                // (the MFMA bursts run at raised priority: a wave with matrix work ready goes before the waves that are
-                // still issuing their fragment reads -- cfg 2 48.77 -> 48.53 ms on the same box, three runs each)
                 frag(s0, 1, a1, b1);
                 __builtin_amdgcn_s_setprio(1);
-                mfma16(a0, b0);
+                mfma_part(a0, b0, I8(), I16());
                 __builtin_amdgcn_s_setprio(0);
                 if (kt + 1 < nk) frag(s1, 0, a0, b0);  // complete since the previous barrier
                 __builtin_amdgcn_s_setprio(1);
-                mfma16(a1, b1);
+                mfma_part(a1, b1, I0(), I16());
                 __builtin_amdgcn_s_setprio(0);
             }
             gwait();
