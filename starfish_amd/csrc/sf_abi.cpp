@@ -795,6 +795,9 @@ static sf_emu_args emu_args(sf_ctx* c, const sf_model_desc* mdl, const double* d
 static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const double* d_params, const Work& w,
                           double* d_flux_out, double* d_X_out, double* d_resid_out, double* d_log_scale,
                           bool want_Y, hipStream_t s) {
+    // (the broadening + spline-fit launches depend on vsini only, not on the emulator; forked onto a stream of their own beside
+    // the emulator's launches and the band fill they do not shorten the banded step: every one of these launches fills the chip
+    // by itself -- with three streams each simply takes longer, profiles/r05_q_banded_step_timelines.txt)
     const int pstride = sf_param_stride(c, mdl);
     SF_HIP(hipMemsetAsync(w.info_e, 0, sizeof(int) * (size_t)B, s));
     int rc = run_emulator(c, mdl, B, d_params, w, w.mu, nullptr, w.Lw, w.info_e, s);
@@ -849,23 +852,6 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
     ev.has_av = mdl->has_av;
     ev.off_av = 6 + c->P + mdl->n_cheb + 3 * mdl->n_local;
     ev.wave_max = c->wave_max;
-    rc = sf_launch_eval_rows(ev, B, s);
-    if (rc) return rc;
-
-    sf_scale_args sc;
-    sc.wave = c->wave.as<double>();
-    sc.dflux = c->flux.as<double>();
-    sc.flux = w.fraw;
-    sc.params = d_params;
-    sc.scale = w.scale;
-    sc.log_scale_out = d_log_scale;
-    sc.n = c->n;
-    sc.ldx = w.L.npad;
-    sc.pstride = pstride;
-    sc.has_log_scale = mdl->has_log_scale;
-    rc = sf_launch_scale(sc, B, s);
-    if (rc) return rc;
-
     sf_resid_args r;
     r.dflux = c->flux.as<double>();
     r.flux = w.fraw;
@@ -883,6 +869,35 @@ static int run_transforms(sf_ctx* c, const sf_model_desc* mdl, int B, const doub
     r.ldx = w.L.npad;
     r.ldy = w.L.npad;
     r.use_sigma_w = mdl->use_sigma_w;
+    if (mdl->has_log_scale) {
+        // the scale factor does not depend on the flux: rows, scale and residual / Y in one pass, X never stored
+        static const bool unfused = SF_TUNE_FLAG("SF_TRANSFORM_UNFUSED");  // (tests: the three launches give the same bits)
+        if (!unfused) {
+            rc = sf_launch_eval_resid_y(ev, r, w.scale, d_log_scale, B, s);
+            if (rc) return rc;
+            if (d_resid_out)
+                SF_HIP(hipMemcpy2DAsync(d_resid_out, sizeof(double) * c->n, w.resid, sizeof(double) * w.L.npad,
+                                        sizeof(double) * c->n, B, hipMemcpyDeviceToDevice, s));
+            return SF_OK;
+        }
+    }
+    rc = sf_launch_eval_rows(ev, B, s);
+    if (rc) return rc;
+
+    sf_scale_args sc;
+    sc.wave = c->wave.as<double>();
+    sc.dflux = c->flux.as<double>();
+    sc.flux = w.fraw;
+    sc.params = d_params;
+    sc.scale = w.scale;
+    sc.log_scale_out = d_log_scale;
+    sc.n = c->n;
+    sc.ldx = w.L.npad;
+    sc.pstride = pstride;
+    sc.has_log_scale = mdl->has_log_scale;
+    rc = sf_launch_scale(sc, B, s);
+    if (rc) return rc;
+
     rc = sf_launch_resid_y(r, B, s);
     if (rc) return rc;
     if (d_resid_out)

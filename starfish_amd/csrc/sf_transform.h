@@ -77,6 +77,10 @@ struct sf_resid_args {
     int n, m, mpad, ldx, ldy, use_sigma_w;
 };
 int sf_launch_resid_y(const sf_resid_args& a, int B, hipStream_t s);
+// eval_rows + scale (given log_scale: spectrum_model.py:316-318) + resid_y in one pass: X and the flux never go through memory
+// (e.X / e.flux / r.X / r.flux / r.scale are not used; `scale_out` [B] and `log_scale_out` [B] or NULL are written)
+int sf_launch_eval_resid_y(const sf_eval_args& e, const sf_resid_args& r, double* scale_out, double* log_scale_out, int B,
+                           hipStream_t s);
 
 int sf_launch_extinct_rows(const double* wave, int n, const double* flux, int rows, double Av, double Rv, int law,
                            double* out, hipStream_t s);  // law: 0 ccm89, 1 odonnell94, 2 calzetti00
