@@ -29,12 +29,10 @@
  *     re-entrant (like the reference's model object).  Every context call makes the context's device
  *     current for the calling thread.  Only the bench timing hooks (sf_profile_*) are process-global
  *     (mutex-protected).
- *   - environment switches (tuning aids, read once): SF_NO_LOOKAHEAD=1 single-stream Cholesky,
- *     SF_CHOL_UNFUSED=1 the round-1 launch sequence (256-column panels, separate panel-solve and
- *     diagonal-update launches) instead of the fused panel kernel, SF_CHOL_GROUPS=1|2 slab groups,
- *     SF_CHOL_SPLIT=n split-K cap, SF_DIAG_SCRATCH=1 the L2-resident diagonal-tile kernel, SF_BAND_NO_TWIST=1
- *     single-sweep banded solver, SF_BAND_TILES_POISON=1 NaN-fills the workspace of the wide-band factorisation
- *     first (test aid); with SF_CHOL_UNFUSED: SF_LEAF_DIAG=1, SF_GEMM_256=1 / SF_GEMM_1024=1 (see sf_chol.hip).
+ *   - the library reads NO environment variable.  (The tuning / timing switches named in starfish_amd/csrc -- SF_CHOL_*,
+ *     SF_DF_*, SF_WIDE_*, ... -- exist only in the separate development build `make -C starfish_amd/csrc TUNING=1`
+ *     (-DSF_TUNING -> libstarfish_amd_tuning.so), which tools/ and two GPU tests load on purpose; the shipped
+ *     libstarfish_amd.so contains no getenv and none of their names: tests/test_host_logic.py checks the binary.)
  */
 #ifndef STARFISH_AMD_H
 #define STARFISH_AMD_H
@@ -57,13 +55,15 @@ extern "C" {
 #define SF_INFO_BAD_VSINI (-2)   /* vsini <= 0: transforms.py:121-122 */
 #define SF_INFO_BAD_WEIGHT_COV (-3) /* Sigma_w not positive definite: spectrum_model.py:334 */
 #define SF_INFO_BANDWIDTH (-4)   /* banded solver only: covariance support wider than the given half-width */
-#define SF_INFO_INTERNAL (-5)    /* a bounded wait between workgroups / waves of ONE launch timed out: the banded sweep's wave
-                                    synchronisation, or a dependency counter of the persistent-kernel Cholesky (the default
-                                    sequence of small batches) -- there EVERY matrix of the call carries the code and no
-                                    result of the call is valid.  Not expected to happen (the schedules are live by construction;
-                                    the bound keeps a logic or hardware error from hanging the GPU).  Callers recover by
-                                    sf_persistent_potrf(0) and re-running the batch (starfish_amd/_device.py does, with a
-                                    warning); it is never to be treated as a rejected walker */
+#define SF_INFO_INTERNAL (-5)    /* a bounded wait between workgroups / waves of ONE launch gave up: the banded sweep's wave
+                                    synchronisation, or the persistent-kernel Cholesky (the default sequence of small batches)
+                                    -- there EVERY matrix of the call carries the code and no result of the call is valid.
+                                    Never seen on a device the process has to itself (the schedule is live by construction);
+                                    on a device SHARED with other processes the launch stalls when workgroups that hold claimed
+                                    tasks are kept from running, and is given up after 25 ms without a single completed task
+                                    (or 4 s in any one wait): see sf_persistent_potrf / sf_persistent_potrf_status.  Callers
+                                    recover by sf_persistent_potrf(0) and re-running the batch (starfish_amd/_device.py does,
+                                    with a warning); it is never to be treated as a rejected walker */
 
 #define SF_INFO_NAN (-6)         /* the likelihood came out NaN although every stage reported success: lnl = -inf, but
                                     distinguishable from a legitimately rejected walker */
@@ -335,9 +335,19 @@ int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, const doubl
  * previous setting.  The recovery path after SF_INFO_INTERNAL.
  * The persistent kernel's workgroups wait for each other inside ONE launch: it assumes the process has the device to itself
  * (one process per GPU).  Several processes oversubscribing one device can keep each other's workgroups from becoming
- * resident; the waits' 4-s bound then aborts the launch (SF_INFO_INTERNAL for the batch) and the caller falls back -- a
- * process that knows it shares its device should switch the sequence off up front. */
+ * running; the launch is then given up FAST -- as soon as no task of it has completed for 25 ms while a workgroup was waiting
+ * (the longest task of the largest matrix the kernel takes, N = 16384, runs ~5 ms), or after 4 s inside one wait --
+ * (SF_INFO_INTERNAL for the batch) and the caller falls back: a shared device costs the first call ~25 ms + one factorisation
+ * on the launch sequences.  A process that knows it shares its device should switch the sequence off up front. */
 int sf_persistent_potrf(int enable);
+
+/* The process's record of persistent-kernel launches, for the caller's warning and for tests (host memory, no
+ * synchronisation: read it after the stream that carried the aborted call has been synchronised):
+ * h_out8 = {aborted launches so far, reason of the last abort (1 = a wait reached its 4-s bound, 2 = no task completed for
+ * 25 ms), workgroups of that launch that had started, its grid size (fewer started than launched = the grid was not
+ * co-resident: the device is shared or partitioned), 100 MHz ticks the reporting wait had lasted, tasks the launch had
+ * completed, persistent launches enqueued by this process so far, 1 if the sequence is enabled}. */
+int sf_persistent_potrf_status(long long* h_out8);
 
 /* Tuning / test aid (process-global): the batched Cholesky has three launch sequences -- the fused panel kernel
  * (128-column panels, two workgroups per CU; medium batches), the unfused one (256-column panels, separate panel-solve and
@@ -346,8 +356,8 @@ int sf_persistent_potrf(int enable);
  * mode -1 = choose by batch and matrix size (default), 0 = always fused, 1 = always unfused, 2 = always wide,
  * 3 = wide for the first half of the panels, then fused (test aid: exercises the hand-over between the two),
  * 4 = dataflow: the whole factorisation as ONE persistent launch whose workgroups draw tasks and wait on exactly the tasks
- * they depend on (the default while batch x 128-column panels <= 2048 and batch <= 128; matrices of more than 65 panels take
- * the fused sequence instead).
+ * they depend on (the default while batch x 128-column panels <= 2048 and batch <= 128; matrices of more than 128 panels
+ * -- N > 16384 -- take the fused sequence instead).
  * The fused and wide sequences factorise matrices of 64 mod 128 rows in a frame shifted by 64 virtual identity rows
  * (addressing only: nothing moves in memory, the caller's layout and the pivot index reported in d_info are unchanged).
  * Same results to rounding. */

@@ -14,8 +14,8 @@ INFO_MESSAGES = {
     -2: "vsini must be positive",
     -3: "emulator weight covariance is not positive definite",
     -4: "covariance support wider than the band half-width given to the banded solver",
-    -5: "internal error: a bounded wait inside a persistent kernel timed out (banded sweep or dataflow Cholesky; "
-        "no result of that call is valid -- please report)",
+    -5: "internal error: a bounded wait inside a persistent kernel gave up (banded sweep or dataflow Cholesky; "
+        "no result of that call is valid -- is the GPU shared with another process?)",
     -6: "the log-likelihood evaluated to NaN (non-finite input or intermediate)",
 }
 INFO_BANDWIDTH = -4
@@ -23,17 +23,33 @@ INFO_INTERNAL = -5
 C_KMS = 2.99792458e5
 
 
+def persistent_status(lib):
+    """``sf_persistent_potrf_status`` as a dict (host memory of the library: read it after the stream was synchronised)."""
+    buf = (C.c_longlong * 8)()
+    _lib.check(lib.sf_persistent_potrf_status(buf), "sf_persistent_potrf_status")
+    keys = ("aborted_launches", "reason", "workgroups_started", "grid", "wait_ticks", "tasks_completed",
+            "launches", "enabled")
+    return dict(zip(keys, (int(v) for v in buf)))
+
+
 def recover_from_internal(lib, where, count):
-    """A dense call came back with SF_INFO_INTERNAL: a wait inside the persistent-kernel Cholesky timed out and the whole
-    batch is invalid (include/starfish_amd.h).  The reference would never turn that into a rejected proposal
-    (spectrum_model.py:400 raises out of cho_factor), so: say so loudly, switch the process to the launch sequences
-    (no waits inside kernels) and let the caller re-run the batch."""
+    """A dense call came back with SF_INFO_INTERNAL: the persistent-kernel Cholesky gave a launch up and the whole batch
+    is invalid (include/starfish_amd.h).  The reference would never turn that into a rejected proposal
+    (spectrum_model.py:400 raises out of cho_factor), so: say so loudly -- with what the aborting workgroup recorded --,
+    switch the PROCESS (all devices, all threads) to the launch sequences (no waits inside kernels) and let the caller
+    re-run the batch."""
     import warnings
 
+    st = persistent_status(lib)
+    why = {1: "a wait between workgroups reached its 4-s bound",
+           2: "no task of the launch completed for 25 ms"}.get(st["reason"], "no abort record")
+    if st["grid"] and st["workgroups_started"] < st["grid"]:
+        why += f"; only {st['workgroups_started']} of its {st['grid']} workgroups had started (grid not co-resident)"
     warnings.warn(
-        f"{where}: internal status -5 for {int(count)} unit(s) -- the persistent-kernel Cholesky aborted a launch; "
-        "it is now disabled for this process (sf_persistent_potrf(0)) and the batch is re-run on the launch sequence. "
-        "Please report this.",
+        f"{where}: internal status -5 for {int(count)} unit(s) -- the persistent-kernel Cholesky gave a launch up ({why}, "
+        f"after {st['tasks_completed']} completed tasks): is this GPU shared with another process?  The kernel assumes "
+        "one process per GPU.  It is now disabled for this whole process, on every device and thread "
+        "(sf_persistent_potrf(0)), and the batch is re-run on the launch sequence.",
         RuntimeWarning,
         stacklevel=3,
     )
@@ -219,6 +235,8 @@ class MultiPlan:
             recover_from_internal(self.lib, "sf_loglike_multi_batch", bad)
             self.enqueue()
             out = collect_multi(self.quad, self.info, self.sizes)
+            if any((o["info"] == INFO_INTERNAL).any() for o in out):  # (never an ordinary per-unit status: nothing is valid)
+                raise RuntimeError(INFO_MESSAGES[INFO_INTERNAL])
         return out
 
 

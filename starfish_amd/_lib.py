@@ -152,6 +152,7 @@ SIGNATURES = {
     "sf_debug_stream_write": (C.c_int, [_VP, C.c_size_t, C.c_double, _VP]),
     "sf_debug_cholesky_sequence": (C.c_int, [C.c_int]),
     "sf_persistent_potrf": (C.c_int, [C.c_int]),
+    "sf_persistent_potrf_status": (C.c_int, [C.POINTER(C.c_longlong)]),
     "sf_profile_enable": (C.c_int, [C.c_int]),
     "sf_profile_read": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
 }
@@ -179,8 +180,17 @@ def load():
 
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        if os.environ.get("SF_LIB_PATH") and not hasattr(lib, name):
-            continue  # (development hook only: an OLDER build of the library in a same-box A/B lacks the newest entry points)
+        if not hasattr(lib, name):
+            # development hook only: an OLDER build of the library in a same-box A/B lacks the newest entry points.  It has
+            # to be asked for (SF_ALLOW_OLD_LIB=1 next to SF_LIB_PATH) and every missing name is reported: a stale or
+            # mismatched library must not load silently and fail later inside an error path.
+            if os.environ.get("SF_LIB_PATH") and os.environ.get("SF_ALLOW_OLD_LIB") == "1":
+                import warnings
+
+                warnings.warn(f"starfish_amd: {LIB_PATH} lacks {name} (SF_ALLOW_OLD_LIB=1: skipped)", RuntimeWarning)
+                continue
+            raise StarfishAMDError(f"{LIB_PATH} does not export {name}: stale or mismatched build of the library "
+                                   "(rebuild with `make -C starfish_amd/csrc`)")
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

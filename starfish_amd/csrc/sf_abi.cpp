@@ -1069,6 +1069,7 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
     Work w = carve(c, mdl, B, d_work, work_bytes, true);
     prof_count_call();
     const int64_t stride = (int64_t)c->npad * c->lda;
+    int call_fp = 0;
     {
         ProfScope ps(s, PS_TRANSFORM);
         rc = run_transforms(c, mdl, B, d_params, w, nullptr, nullptr, d_resid, d_log_scale, true, s);
@@ -1087,8 +1088,12 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
         f.tilelist = w.tilelist;
         f.tilecount = w.tilecount;
         f.list_cap = (int)tilemap_bytes(layout_of(c));
-        f.fp = sf_potrf_front_pad(c->npad, B);  // (the tiles of the factorisation's frame: see sf_potrf_front_pad)
+        // (the tiles of the factorisation's frame: see sf_potrf_front_pad.  Evaluated ONCE per call and handed on to the
+        // factorisation below: it depends on the process-global persistent-kernel switch, which a recovery on another host
+        // thread may flip between the two stages -- tile map and factorisation must agree on the frame)
+        f.fp = sf_potrf_front_pad(c->npad, B);
         f.nt128 = (c->npad + f.fp + 127) / 128;
+        call_fp = f.fp;
         rc = sf_launch_fill(f, B, s);
         if (rc) return rc;
     }
@@ -1100,7 +1105,7 @@ extern "C" int sf_loglike_batch(sf_ctx* c, const sf_model_desc* mdl, int B, cons
         gen.mpad = c->mpad;
         gen.ldy = c->npad;
         gen.tilemap = w.tilemap;
-        gen.fp = sf_potrf_front_pad(c->npad, B);
+        gen.fp = call_fp;
         gen.nt128 = (c->npad + gen.fp + 127) / 128;
         rc = sf_launch_potrf(w.C, c->npad, c->lda, stride, B, w.info_c, w.ltbuf, w.resid, c->npad, s, &gen, &c->exec);
         if (rc) return rc;
@@ -1714,6 +1719,13 @@ extern "C" int sf_emulator_v11_build(const double* d_grid, int M, int P, int m, 
 // Recovery switch of the callers (process-global): after a batch came back SF_INFO_INTERNAL the host layer turns the
 // persistent-kernel sequence off and re-runs the batch on a launch sequence (starfish_amd/_device.py).
 extern "C" int sf_persistent_potrf(int enable) { return sf_set_persistent_potrf(enable); }
+extern "C" int sf_persistent_potrf_status(long long* h_out8) {
+    if (!h_out8) {
+        sf_set_error("sf_persistent_potrf_status: h_out8 is required");
+        return SF_EINVAL;
+    }
+    return sf_persistent_potrf_read_status(h_out8);
+}
 
 // Tuning / test aid: pin the launch sequence of the batched Cholesky (process-global).
 extern "C" int sf_debug_cholesky_sequence(int mode) { return sf_set_cholesky_sequence(mode); }

@@ -1303,17 +1303,45 @@ __device__ __forceinline__ void sf_solve_step(sf_d4 (&acc)[2][4], const double* 
 // (/opt/skills/guides/MI355X_MICROARCH.md, "Valid forms".)  Every wait is bounded: after SF_DF_TIMEOUT_TICKS of the 100 MHz
 // wall clock the waiter raises the launch's abort flag, which every other wait and the task dispenser observe.
 #define SF_DF_TIMEOUT_TICKS 400000000LL  // 4 s
+// ... and the launch is also aborted when NO task of the launch has completed for SF_DF_STALL_TICKS while a workgroup was
+// waiting (round 6): every task end bumps a progress counter (abort_flag[5]); the longest task of the largest matrix the tables
+// hold (N = 16384: one slab's 1024 K slabs) runs ~5 ms, so 25 ms without a single completion chip-wide means the workgroups
+// that hold the claimed tasks are not running -- a device shared with other processes (profiles/r05_g_shared_gpu_abort.txt: the
+// stall begins mid-launch, an arrival gate at the head of the kernel would not see it).  The caller's fall-back then costs
+// ~25 ms + one factorisation on the launch sequences instead of 4 s.  abort_flag[6] counts the workgroups that started (a
+// diagnostic: grid not co-resident), abort_flag[7] != 0 replaces the bound (units of 2^16 ticks; tuning builds).
+#define SF_DF_STALL_TICKS 2500000LL  // 25 ms
+#define SF_DF_ABORT_TIMEOUT 1
+#define SF_DF_ABORT_STALL 2
 __device__ __forceinline__ int sf_df_load(const int* flag) {
     return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the waiter that raises the abort flag leaves what it was waiting for behind it: abort_flag[1..] = {counter (offset from the abort
 // flag, in ints), target, value} of the first counter that had not arrived (tuning builds print it)
-__device__ __forceinline__ void sf_df_report(int* abort_flag, const int* f, int target) {
-    if (__hip_atomic_exchange(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && f) {
-        abort_flag[1] = (int)(f - abort_flag);
-        abort_flag[2] = target;
-        abort_flag[3] = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// (abort_flag[8..9]: address of the process's abort record in host memory, sf_df_diag -- what the caller's warning quotes:
+// {aborted launches, reason, workgroups that had started, grid, ticks the reporting wait had lasted, tasks completed})
+__device__ __forceinline__ void sf_df_report(int* abort_flag, const int* f, int target, int reason = SF_DF_ABORT_TIMEOUT,
+                                             long long waited = 0) {
+    if (__hip_atomic_exchange(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (f) {
+            abort_flag[1] = (int)(f - abort_flag);
+            abort_flag[2] = target;
+            abort_flag[3] = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        long long* diag = (long long*)__hip_atomic_load((long long*)(abort_flag + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (diag) {
+            diag[1] = reason;
+            diag[2] = sf_df_load(abort_flag + 6);
+            diag[3] = gridDim.x;
+            diag[4] = waited;
+            diag[5] = sf_df_load(abort_flag + 5);
+            __hip_atomic_fetch_add(diag, 1LL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
+}
+__device__ __forceinline__ long long sf_df_stall_ticks(const int* abort_flag) {
+    const int o = abort_flag[7];
+    return o ? (long long)o << 16 : SF_DF_STALL_TICKS;
 }
 // Waits until *f1 >= t1 and *f2 >= t2 and *f3 >= t3 (NULL flags are skipped), then ONE acquire for all of them.  `probe`
 // (optional) is only looked at, before the acquire: *probe_ok tells whether it had reached its target -- the data it guards
@@ -1345,6 +1373,8 @@ __device__ __forceinline__ int sf_df_wait_r(const int* f1, int t1, const int* f2
         };
         if (!ready()) {
             const long long t0 = wall_clock64();
+            long long tp = t0;                       // when the launch's progress counter last moved, as seen from this wait
+            int pg0 = sf_df_load(abort_flag + 5);
             unsigned it = 0;
             for (;;) {
                 __builtin_amdgcn_s_sleep(4);
@@ -1354,11 +1384,22 @@ __device__ __forceinline__ int sf_df_wait_r(const int* f1, int t1, const int* f2
                         ok = 0;
                         break;
                     }
-                    const long long waited = wall_clock64() - t0;
+                    const long long now = wall_clock64();
+                    const long long waited = now - t0;
+                    const int pg = sf_df_load(abort_flag + 5);
+                    if (pg != pg0) {
+                        pg0 = pg;
+                        tp = now;
+                    } else if (now - tp > sf_df_stall_ticks(abort_flag)) {  // nothing completes any more: see SF_DF_STALL_TICKS
+                        const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
+                        sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3), SF_DF_ABORT_STALL, waited);
+                        ok = 0;
+                        break;
+                    }
                     // (abort_flag[4]: the bound in units of 2^20 ticks when the host asked for another one -- tuning builds)
                     if (waited > SF_DF_TIMEOUT_TICKS && (abort_flag[4] == 0 || (waited >> 20) > abort_flag[4])) {
                         const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
-                        sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3));
+                        sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3), SF_DF_ABORT_TIMEOUT, waited);
                         ok = 0;
                         break;
                     }
@@ -2915,8 +2956,7 @@ static int sf_launch_potrf_v2(double* A, int n, int lda, int64_t stride, int bat
 // tail_rounds: the pairs whose wide launches have at most this many rounds of workgroups left (and everything after them)
 // are single narrow steps; -1 = wide to the end; -2 = switch half-way (test aid: exercises the hand-over on any size).
 static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
-                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex, int tail_rounds, int fp,
-                              int head_panels = 0) {
+                              double* rhs, int ldr, hipStream_t s, const sf_gen_args* gen, sf_exec* ex, int tail_rounds, int fp) {
     if (n % SF_LEAF != 0 || lda < n || batch <= 0 || (lda & 1) || !work) {
         sf_set_error("potrf: n must be a positive multiple of %d, lda >= n and even, workspace required", SF_LEAF);
         return SF_EINVAL;
@@ -3136,9 +3176,10 @@ static int sf_launch_potrf_v3(double* A, int n, int lda, int64_t stride, int bat
     // triangular solves, tile out, one after the other with nothing beside it on the CU (B = 128: pair 0 runs at 0.44 of
     // the matrix peak, pair 1 at 0.65, pair 2 at 0.70; the pairs from K = 1024 on at 0.81-0.88,
     // profiles/r05_d_wide_per_pair_b128.txt).  The panels left of `head` are narrow steps (two workgroups per CU overlap
-    // one's memory phases with the other's solves).
-    static const int head_env = SF_TUNE_INT("SF_WIDE_HEAD", -1);
-    const int head = std::min(nt, (head_env >= 0 ? head_env : head_panels) & ~1);
+    // one's memory phases with the other's solves) -- in tuning builds only: measured without gain for head = 2 ... 12
+    // (profiles/r05_d_wide_narrow_head_sweep.txt), the release library always starts with pair 0.
+    static const int head_env = SF_TUNE_INT("SF_WIDE_HEAD", 0);
+    const int head = std::min(nt, std::max(head_env, 0) & ~1);
     int k = 0;
     for (; k < head; ++k) SF_TRY(narrow_step(k));
     bool handover = head > 0;
@@ -3430,8 +3471,9 @@ struct sf_df_args {
     int64_t sT;
     double* part;     // three regions of sf_split_region_tiles() tiles: rest partial sums by stage parity, front partial sums
     int* info;
+    long long* diag;  // the process's abort record in host memory (sf_df_diag), or NULL
     long long* dbg;   // tuning builds: per workgroup {ticks waiting, ticks in task bodies, tasks, ticks by type} (100 MHz)
-    int miss_claims;  // tuning builds (SF_DF_MISS_CLAIMS): the dispenser leaves chain / front tasks to the waits' rescue while its queues hold tasks
+    int miss_claims;  // tuning builds (SF_DF_MISS_CLAIMS): 1 = the dispenser leaves chain / front tasks to the waits' rescue while its queues hold tasks; 2 = a claimed chain task is never run (forces the stall bound)
     long long* trace; // tuning builds (SF_DF_TRACE_FILE): [0] = records written, then {type | k << 8 | i << 16 | b << 24 | workgroup << 40, claimed, body start, end}
     long long trace_cap;
     sf_df_stage_packed st[2][SF_DF_MAX_STAGES];
@@ -3449,7 +3491,7 @@ typedef const __attribute__((address_space(4))) sf_df_args sf_df_kargs;
 #define SF_DF_HELPER __attribute__((noinline))
 #endif
 #ifdef SF_TUNING
-#define SF_DF_MISS_CLAIMS(x) (a.miss_claims && (x))
+#define SF_DF_MISS_CLAIMS(x) ((a.miss_claims & 1) && (x))
 #else
 #define SF_DF_MISS_CLAIMS(x) (false)
 #endif
@@ -3509,7 +3551,13 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
     int qcur = (int)(blockIdx.x & (SF_DF_QUEUES - 1));
     int visited = 0;
     int kst = 0;  // stage hint: a workgroup draws the tasks of a queue in increasing order
-    if (threadIdx.x == 0) s_ints[5] = 0;  // (idle spell of the end-of-launch phase, see the dispenser)
+    if (threadIdx.x == 0) {
+        s_ints[5] = 0;  // (idle spell of the end-of-launch phase, see the dispenser)
+        s_ints[6] = 0;
+        sf_df_add(ap->abort_flag + 6, 1);  // workgroups of the launch that have started (diagnostic of an aborted launch)
+        if (blockIdx.x == 0)  // (where sf_df_report finds the abort record: the waits only carry the abort flag's address)
+            __hip_atomic_store((long long*)(ap->abort_flag + 8), (long long)ap->diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // A queued task whose wait was interrupted to run a chain / front task nobody had claimed (sf_df_wait_r): resume = 1 the
     // claimed chain task is in s_ints[0..4] already; pend_t >= 0: that queued task is taken up again instead of a new one.
     int pend_t = -1, resume = 0;
@@ -3565,11 +3613,19 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                             t = -5;
                         } else {
                             // (bounded like every wait: chains that stay open with nothing left to run them would spin here for ever)
-                            // (s_ints[5]: the 10.5 ms unit of the wall clock at which this idle spell began, + 1; 0 = none)
+                            // (s_ints[5]: the 10.5 ms unit of the wall clock at which this idle spell began -- or the launch's
+                            // progress counter, s_ints[6], last moved --, + 1; 0 = none.  No task completed for three units, 21-31
+                            // ms: SF_DF_STALL_TICKS)
                             const int now = (int)((wall_clock64() >> 20) & 0x3fffffff) + 1;
-                            if (s_ints[5] == 0) s_ints[5] = now;
-                            if (((now - s_ints[5]) & 0x3fffffff) > (a.abort_flag[4] ? a.abort_flag[4] : (int)(SF_DF_TIMEOUT_TICKS >> 20))) {
-                                sf_df_report(a.abort_flag, a.chain_next, nt);
+                            const int pg = sf_df_load(a.abort_flag + 5);
+                            if (s_ints[5] == 0 || pg != s_ints[6]) {
+                                s_ints[5] = now;
+                                s_ints[6] = pg;
+                            }
+                            const int idle = (now - s_ints[5]) & 0x3fffffff;
+                            const int stall = (int)(sf_df_stall_ticks(a.abort_flag) >> 20);
+                            if (idle > stall) {
+                                sf_df_report(a.abort_flag, a.chain_next, nt, SF_DF_ABORT_STALL, (long long)idle << 20);
                                 t = -1;
                             }
                             __builtin_amdgcn_s_sleep(64);
@@ -3661,6 +3717,17 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
         d = __builtin_amdgcn_readfirstlane(d);
         type = __builtin_amdgcn_readfirstlane(type);
         const int b = bchain >= 0 ? bchain : qcur + SF_DF_QUEUES * bl;  // the matrix
+#ifdef SF_TUNING
+        // test aid (SF_DF_MISS_CLAIMS=2): the workgroup that claimed the chain task of panel 2 of matrix 0 never runs it --
+        // what a workgroup that is kept from running looks like to the others: everything downstream waits, no task
+        // completes any more, the stall bound gives the launch up (tests/test_gpu_recovery.py)
+        if ((a.miss_claims & 2) && type == T_C && b == 0 && k == 2) {
+            if (tid == 0)
+                while (sf_df_load(a.abort_flag) == 0) __builtin_amdgcn_s_sleep(64);
+            __syncthreads();
+            continue;
+        }
+#endif
         const int vb = bchain >= 0 ? (((a.batch - (b & (SF_DF_QUEUES - 1)) + SF_DF_QUEUES - 1) / SF_DF_QUEUES) == a.bq[0] ? 0 : 1) : v;  // its queue's table
 #ifdef SF_TUNING
         const long long dbg_t0 = wall_clock64();
@@ -3739,6 +3806,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 if (tid == 0) {
                     sf_df_release();
                     sf_df_set(a.done_row + (size_t)b * nt + slab, kp + 1);
+                    sf_df_add(a.abort_flag + 5, 1);  // (progress of the launch: see SF_DF_STALL_TICKS)
                 }
             }
             if (ok && type == T_C) {
@@ -3764,6 +3832,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 if (tid == 0) {
                     sf_df_release();
                     sf_df_set(a.done_D + b, k + 1);
+                    sf_df_add(a.abort_flag + 5, 1);
                 }
             }
             if (type == T_C) __builtin_amdgcn_s_setprio(0);
@@ -3876,6 +3945,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     sf_df_set(rowflag, k + 1);
                     if (type == T_RR) sf_df_add(sdone + k, 1);
                 }
+                sf_df_add(a.abort_flag + 5, 1);
             }
         }
         if (!ok) continue;  // (timed out: the dispenser sees the abort flag and flags every matrix)
@@ -3920,6 +3990,36 @@ static int sf_df_split(long long tasks, int nk, int smax, int cap) {
     int S = 1;
     while (2 * S <= smax && tasks * 2 * S <= cap && nk / (2 * S) >= 8) S *= 2;
     return S;
+}
+
+static int g_df_enabled_query(void);
+// The abort record of the process: six long longs of pinned host memory that the workgroup which aborts a persistent launch
+// fills in (sf_df_report) and sf_persistent_potrf_status() hands to the caller's warning -- the status itself travels in
+// d_info like every other (SF_INFO_INTERNAL).  Allocated on the first persistent launch; visible to every device.
+static long long* g_df_diag = nullptr;
+static std::atomic<long long> g_df_launches{0};
+static long long* sf_df_diag(void) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!g_df_diag) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 8 * sizeof(long long), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;  // (no record then: the launch itself does not depend on it)
+        }
+        for (int i = 0; i < 8; ++i) ((volatile long long*)p)[i] = 0;
+        g_df_diag = (long long*)p;
+    }
+    return g_df_diag;
+}
+int sf_persistent_potrf_read_status(long long* out8) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    const volatile long long* d = g_df_diag;
+    for (int i = 0; i < 6; ++i) out8[i] = d ? d[i] : 0;
+    out8[6] = g_df_launches.load();
+    out8[7] = g_df_enabled_query();
+    return SF_OK;
 }
 
 static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int batch, int* info, double* work,
@@ -3971,6 +4071,11 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     if (SF_TUNE_FLAG("SF_DF_FORCE_ABORT")) SF_HIP(hipMemsetAsync(a.abort_flag, 1, 1, s));
     static const int timeout_s = SF_TUNE_INT("SF_DF_TIMEOUT_S", 0);  // (bound of the waits in seconds instead of 4)
     if (timeout_s > 0) SF_HIP(hipMemsetD32Async((hipDeviceptr_t)(a.abort_flag + 4), timeout_s * 95, 1, s));
+    // (no-progress bound in ms instead of 25; with SF_DF_TIMEOUT_S alone the stall bound follows it: the experiment that showed
+    // the shared-device deadlock to be one -- a launch still stuck after 60 s -- stays reproducible)
+    static const int stall_ms = SF_TUNE_INT("SF_DF_STALL_MS", 0);
+    const long long stall_units = stall_ms > 0 ? ((long long)stall_ms * 100000) >> 16 : (timeout_s > 0 ? ((long long)timeout_s * 100000000) >> 16 : 0);
+    if (stall_units > 0) SF_HIP(hipMemsetD32Async((hipDeviceptr_t)(a.abort_flag + 7), (int)std::min<long long>(stall_units, 0x7fffffff), 1, s));
     a.miss_claims = SF_TUNE_INT("SF_DF_MISS_CLAIMS", 0);
 #endif
 
@@ -4030,6 +4135,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.sT = sT;
     a.part = part;
     a.info = info;
+    a.diag = sf_df_diag();
 #ifdef SF_TUNING
     if (SF_TUNE_FLAG("SF_DF_VERBOSE")) a.dbg = (long long*)(flags + ((nflags - ndbg + 1) & ~(size_t)1));
     static const char* trace_file = SF_TUNE_STR("SF_DF_TRACE_FILE");  // every task's {what, claimed, body start, end} as text
@@ -4124,6 +4230,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
         hipLaunchKernelGGL(k_potrf_dataflow<true>, dim3(grid), dim3(512), SF_DF_LDS_BYTES, s, a);
     else
         hipLaunchKernelGGL(k_potrf_dataflow<false>, dim3(grid), dim3(512), SF_DF_LDS_BYTES, s, a);
+    g_df_launches.fetch_add(1);
     sf_prof_gemm_end(tok);
     SF_LAUNCH_CHECK();
 #ifdef SF_TUNING
@@ -4226,13 +4333,19 @@ static std::atomic<int> g_df_enabled{1};
 int sf_set_persistent_potrf(int enable) {
     return enable < 0 ? g_df_enabled.load() : g_df_enabled.exchange(enable ? 1 : 0);
 }
+static int g_df_enabled_query(void) { return g_df_enabled.load(); }
 static bool sf_potrf_dataflow_fits(int n, int batch) {
-    const int nt = (n + 64 + GT - 1) / GT;  // (panels of the shifted frame at most)
+    // panels: n is a multiple of 64; an order of 64 mod 128 rows has (n + 64) / 128 of them in either frame (shifted by 64
+    // virtual rows, sf_potrf_front_pad, or not) -- N = 16384 is 128 panels = 127 stages, the tables' limit (the round-5 check
+    // added the 64 rows unconditionally: 129 panels, so N = 16384 never took the persistent kernel, forced or not)
+    const int nt = (n + GT - 1) / GT;
     return g_df_enabled.load() && nt - 1 <= SF_DF_MAX_STAGES && 2 * (size_t)SF_DF_FRONT_WIDEST * batch <= sf_split_region_tiles();
 }
 static bool sf_potrf_dataflow_auto(int n, int batch) {
     static const int lim = SF_TUNE_INT("SF_DF_BELOW", 2048);
-    const int nt = (n + 64 + GT - 1) / GT;  // (panels of the shifted frame at most)
+    // (the measured dispatch rule counts panels conservatively, with 64 virtual rows: at N = 4096 it is 33 x batch <= 2048,
+    // i.e. up to 62 matrices)
+    const int nt = (n + 64 + GT - 1) / GT;
     return sf_potrf_dataflow_fits(n, batch) && (long long)batch * nt <= lim && batch <= 128;
 }
 int sf_potrf_front_pad(int n, int batch) {

@@ -130,6 +130,7 @@ int sf_launch_potrf_band(int n, int nband, int halfwidth, int batch, const doubl
                          int nrhs, int ldr, int64_t srhs, double* logdet, double* gram, int* info, double* tiles,
                          hipStream_t s);
 int sf_set_persistent_potrf(int enable);  // 0 / 1: the dataflow sequence may be chosen; < 0: query.  Returns the previous value
+int sf_persistent_potrf_read_status(long long* out8);  // sf_persistent_potrf_status (include/starfish_amd.h)
 int sf_set_cholesky_sequence(int mode);  // -1 automatic (by batch size), 0 fused panel kernel, 1 unfused
 int sf_launch_logdet_z(const double* L, int n, int lda, int64_t stride, int batch, const double* z, int ldr,
                        double* logdet, double* sqmah, hipStream_t s);

@@ -465,9 +465,20 @@ class SpectrumModel:
         self.last_info = info
         return (lnl, info) if return_info else lnl
 
-    def train(self, priors=None, **kwargs):
-        """MAP estimate by Nelder-Mead over :meth:`log_likelihood` (spectrum_model.py:635-696)."""
+    def train(self, priors=None, batch_simplex=True, **kwargs):
+        """MAP estimate by Nelder-Mead over :meth:`log_likelihood` (spectrum_model.py:635-696).  ``kwargs`` go to
+        ``scipy.optimize.minimize`` as in the reference.
+
+        The reference's loop is ~10^3 SERIAL scalar evaluations.  Here (``batch_simplex=True``, a plain Nelder-Mead run:
+        no other ``method``, no bounds) the candidate points of every simplex iteration -- reflection, expansion, both
+        contractions: all functions of the current simplex -- are evaluated as ONE device batch of four, the initial
+        simplex and every shrink step as one batch each (:mod:`starfish_amd._neldermead`); the accept / contract / shrink
+        decisions, their order, ``nit`` / ``nfev`` / ``status`` and the exceptions of invalid points are scipy's.  The
+        state the model is left in is the reference's too: the parameters, caches, ``residuals`` entry and
+        ``_lnprob`` of the LAST point the objective was asked for, then ``soln.x`` if the run succeeded."""
         from scipy.optimize import minimize
+
+        from .._neldermead import minimize_neldermead_batched, split_minimize_kwargs
 
         priors = {} if priors is None else priors
         for key, val in priors.items():
@@ -483,9 +494,25 @@ class SpectrumModel:
             self.set_param_vector(P)
             return -self.log_likelihood(priors)
 
-        opts = {"method": "Nelder-Mead"}
-        opts.update(kwargs)
-        soln = minimize(nll, self.get_param_vector(), **opts)
+        nm_opts, why_not = split_minimize_kwargs(kwargs) if batch_simplex else (None, "batch_simplex=False")
+        if nm_opts is None:
+            self.log.debug(f"train: serial scipy path ({why_not})")
+            opts = {"method": "Nelder-Mead"}
+            opts.update(kwargs)
+            soln = minimize(nll, self.get_param_vector(), **opts)
+        else:
+            def nll_batch(X):
+                lnl, info = self.log_likelihood_batch(X, priors, return_info=True)
+
+                def raiser(i):  # the scalar objective raises for these (spectrum_model.py:400, emulator.py:377-378, ...)
+                    self._raise_for_info(info[i])
+
+                return -lnl, raiser
+
+            soln = minimize_neldermead_batched(nll_batch, self.get_param_vector(), **nm_opts)
+            # leave the model where the reference's last objective call left it (parameters, frozen-cache snapshots, the
+            # residual deque, _lnprob): ONE scalar evaluation at that point
+            nll(soln.last_x)
         if soln.success:
             self.set_param_vector(soln.x)
         return soln

@@ -200,3 +200,109 @@ def test_chain_tasks_claimed_only_by_the_rescue_of_the_waits_give_the_same_facto
     for key in want:
         assert got[key]["info"] == [0] * len(got[key]["info"])
         assert got[key] == want[key], key
+
+
+_STALL = r"""
+import json, time, warnings, numpy as np, torch
+from starfish_amd import _device as D, _lib, synth
+lib = _lib.require_gpu()
+dev = D.device_of()
+N, B = 2048, 4
+lda = N + 16
+g = torch.Generator(device=dev).manual_seed(7)
+A = torch.empty((B, N, lda), dtype=torch.float64, device=dev).normal_(generator=g) * 0.01
+A[:, :, :N] = A[:, :, :N] + A[:, :, :N].transpose(1, 2) + torch.eye(N, dtype=torch.float64, device=dev) * 4.0
+info = torch.empty((B,), dtype=torch.int32, device=dev)
+ws = D.workspace(lib.sf_potrf_workspace_bytes(N, B), dev)
+assert lib.sf_debug_cholesky_sequence(4) == 0
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+_lib.check(lib.sf_potrf_batch(D.ptr(A), N, lda, N * lda, B, D.ptr(info), D.ptr(ws), ws.numel(), D.stream_ptr(dev)))
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+st = D.persistent_status(lib)
+lib.sf_debug_cholesky_sequence(-1)
+# ... and through the product: the first batch of a model meets the same stall, warns, is re-run
+o = synth.make_order(N=1024, m=4, seed=5)
+model = synth.build_model(o)
+P = synth.walker_ball(o, B=16, seed=3)
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    t0 = time.perf_counter()
+    lnl, minfo = model.log_likelihood_batch(P, return_info=True)
+    dt_model = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    again = model.log_likelihood_batch(P)
+    dt_again = time.perf_counter() - t0
+print(json.dumps(dict(info=info.cpu().tolist(), seconds=dt, status=st, lnl=lnl.tolist(), again=again.tolist(), minfo=minfo.tolist(),
+                      dt_model=dt_model, dt_again=dt_again, enabled=lib.sf_persistent_potrf(-1),
+                      warned=[str(x.message) for x in w if issubclass(x.category, RuntimeWarning)])))
+"""
+
+
+def test_a_launch_whose_claimed_task_never_runs_is_given_up_within_the_stall_bound_not_after_four_seconds():
+    """What a device shared with other processes does to the persistent kernel (profiles/r05_g_shared_gpu_abort.txt): a workgroup
+    that has claimed a task is kept from running, everything downstream waits.  Forced here (tuning build, SF_DF_MISS_CLAIMS=2:
+    the chain task of panel 2 of matrix 0 is claimed and never run).  Round 5 gave such a launch up after the 4-s bound of a
+    single wait; now the waits watch the launch's progress counter and give up once NO task has completed for 25 ms.  The
+    record of the abort (sf_persistent_potrf_status) says why; the host layer's fall-back makes the model's first call cost
+    well under a second and warns once."""
+    got, _ = _run(_STALL, SF_DF_MISS_CLAIMS="2")
+    assert got["info"] == [-5] * 4
+    st = got["status"]
+    assert st["aborted_launches"] == 1 and st["reason"] == 2, st   # no task completed for 25 ms
+    assert st["workgroups_started"] == st["grid"] > 0, st          # (an exclusive box: the whole grid was resident)
+    assert 0 < st["tasks_completed"] < 200, st
+    assert got["seconds"] < 0.5, got["seconds"]                    # 25-35 ms of stall + the launch, not 4 s
+    assert got["minfo"] == [0] * 16 and np.isfinite(got["lnl"]).all()
+    assert len(got["warned"]) == 1 and "no task of the launch completed for 25 ms" in got["warned"][0], got["warned"]
+    assert "disabled for this whole process" in got["warned"][0]
+    assert got["enabled"] == 0 and got["lnl"] == got["again"]
+    assert got["dt_model"] < 1.0, got["dt_model"]
+    clean, _ = _run(_MODEL.replace("lib = _lib.require_gpu()", "lib = _lib.require_gpu(); lib.sf_persistent_potrf(0)"))
+    assert got["lnl"] == clean["lnl"]  # the values of the launch sequences, bit for bit
+
+
+def test_n16384_forced_sequence_4_really_launches_the_persistent_kernel():
+    """Round 5's fit check counted 129 panels for N = 16384 (64 rows of shifted frame added unconditionally), so the matrix of
+    cfg 5 never took the persistent kernel although its tables hold 127 stages (advisor, round 5).  The library counts its
+    persistent launches: one more after this call, none when the sequence is switched off; factors equal to the fused
+    sequence's to rounding."""
+    import torch
+    from starfish_amd import _device as D, _lib
+
+    lib = _lib.require_gpu()
+    dev = D.device_of()
+    N, B = 16384, 2
+    lda = N + 16
+    g = torch.Generator(device=dev).manual_seed(11)
+    # (only the lower triangle is referenced: random entries of standard deviation 0.003 below a diagonal of 4 -- the
+    # symmetric matrix they define has spectral radius ~ 4 +- 0.8)
+    A0 = torch.empty((B, N, lda), dtype=torch.float64, device=dev).normal_(generator=g) * 0.003
+    for b in range(B):
+        A0[b, :, :N].diagonal().add_(4.0 + 0.1 * b)
+    info = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = D.workspace(lib.sf_potrf_workspace_bytes(N, B), dev)
+    out = {}
+    try:
+        for seq in (4, 0):
+            A = A0.clone()
+            assert lib.sf_debug_cholesky_sequence(seq) in (-1, 0, 4)
+            before = D.persistent_status(lib)["launches"]
+            _lib.check(lib.sf_potrf_batch(D.ptr(A), N, lda, N * lda, B, D.ptr(info), D.ptr(ws), ws.numel(), D.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            assert info.cpu().tolist() == [0] * B
+            out[seq] = (D.persistent_status(lib)["launches"] - before, torch.tril(A[:, :, :N]).clone())
+            del A
+    finally:
+        lib.sf_debug_cholesky_sequence(-1)
+    assert out[4][0] == 1 and out[0][0] == 0
+    L4, L0 = out[4][1], out[0][1]
+    assert float((L4 - L0).abs().max()) <= 1e-11 * float(L0.abs().max())
+    # L L^T = A on a row block (the factor itself, not only agreement between two sequences)
+    r0, r1 = 9000, 9128
+    want = torch.tril(A0[0, :, :N])[r0:r1, :].clone()
+    want[:, r0:] = torch.tril(A0[0, r0:, r0:N]).T[: r1 - r0, :]  # (columns right of the diagonal: the transposed lower part)
+    want[:, r0:r1] = torch.tril(A0[0, r0:r1, r0:r1]) + torch.tril(A0[0, r0:r1, r0:r1], -1).T
+    got = L4[0, r0:r1, :] @ L4[0].T
+    assert float((got - want).abs().max()) < 1e-11

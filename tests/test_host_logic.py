@@ -318,3 +318,33 @@ def test_release_library_has_no_environment_switches():
             for ln in open(os.path.join(csrc, f)):
                 if "getenv" in ln:
                     assert f == "sf_common.h" and "#define SF_TUNE_" in ln, (f, ln)
+
+
+def test_a_library_that_lacks_a_declared_entry_point_does_not_load_silently(monkeypatch):
+    """Advisor, round 5: with SF_LIB_PATH set, load() used to skip any missing symbol, so a stale build loaded without
+    complaint and failed later inside an error path.  A missing symbol now raises at load time; an OLDER build for a
+    same-box A/B has to be asked for (SF_ALLOW_OLD_LIB=1) and every skipped name is reported."""
+    from starfish_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setitem(_lib.SIGNATURES, "sf_entry_point_of_a_newer_header", (None, []))
+    monkeypatch.delenv("SF_ALLOW_OLD_LIB", raising=False)
+    with pytest.raises(_lib.StarfishAMDError, match="does not export sf_entry_point_of_a_newer_header"):
+        _lib.load()
+    monkeypatch.setenv("SF_LIB_PATH", _lib.LIB_PATH)
+    with pytest.raises(_lib.StarfishAMDError, match="stale or mismatched"):
+        _lib.load()  # (the development hook alone does not relax it)
+    monkeypatch.setenv("SF_ALLOW_OLD_LIB", "1")
+    with pytest.warns(RuntimeWarning, match="lacks sf_entry_point_of_a_newer_header"):
+        assert _lib.load() is not None
+    monkeypatch.setattr(_lib, "_lib", None)
+
+
+def test_header_documents_no_environment_switch_and_the_persistent_kernel_status():
+    text = open(os.path.join(ROOT, "include", "starfish_amd.h")).read()
+    assert "environment switches (tuning aids, read once)" not in text
+    assert "reads NO environment variable" in text
+    assert "sf_persistent_potrf_status" in text and "25 ms" in text
+    blob = open(os.path.join(ROOT, "starfish_amd", "libstarfish_amd.so"), "rb").read()
+    for name in (b"SF_DF_STALL_MS", b"SF_DF_MISS_CLAIMS", b"SF_DF_TIMEOUT_S", b"SF_WIDE_HEAD", b"getenv"):
+        assert name not in blob, name
