@@ -475,6 +475,86 @@ def fill_leg(w, steps=5, warmup=2):
     }
 
 
+def sampler_leg(w, steps=10, warmup=2):
+    """What an emcee-style loop actually issues (reference caller: examples/single.ipynb:458-466, 528-546):
+    a stretch-move ensemble of `w.B` walkers advances by TWO dependent half-ensemble calls per step, each through the drop-in
+    front-end SpectrumModel.log_likelihood_batch(P, priors) -- host-side packing of the proposals, priors, upload, the hot
+    path on B / 2 walkers, download -- plus the sampler's own host arithmetic.  Reported: evaluations per second of the
+    loop, the host time per step outside the device calls, and the ratio to the headline rate (one call of B walkers)."""
+    import numpy as np
+    import scipy.stats as st
+    import torch
+
+    from starfish_amd import samplers, synth
+
+    model, dev = w.model, w.dev
+    labels = model.labels
+    c = dict(zip(labels, synth.centre_vector(w.order0)))
+    priors = {"T": st.uniform(c["T"] - 100, 200), "logg": st.uniform(c["logg"] - 0.5, 1.0), "Z": st.uniform(c["Z"] - 0.5, 1.0),
+              "vsini": st.uniform(0, 500), "vz": st.norm(c["vz"], 50.0), "global_cov:log_amp": st.norm(c["global_cov:log_amp"], 5.0),
+              "global_cov:log_ls": st.uniform(0, 10)}
+    t_dev = [0.0, 0]
+    inner = dev.loglike
+
+    def timed_loglike(*a, **k):  # (wall time of the device call as the front-end sees it: enqueue + synchronise + copies)
+        t0 = time.perf_counter()
+        try:
+            return inner(*a, **k)
+        finally:
+            t_dev[0] += time.perf_counter() - t0
+            t_dev[1] += 1
+
+    dev.loglike = timed_loglike
+    try:
+        nw = w.B
+        sampler = samplers.EnsembleSampler(nw, len(labels), lambda P: model.log_likelihood_batch(P, priors), seed=3)
+        x = synth.walker_ball(w.order0, B=nw, seed=1)
+        x, _ = sampler.run_mcmc(x, warmup)
+        torch.cuda.synchronize()
+        t_dev[:] = [0.0, 0]
+        t0 = time.perf_counter()
+        x, lp = sampler.run_mcmc(x, steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        dev.loglike = inner
+    evals = (steps + 1) * nw  # (run_mcmc evaluates its start first: one call of all walkers, inside the timed region)
+    calls = t_dev[1]
+    return {"walkers": nw, "steps": steps, "evals_per_s": evals / dt, "ms_per_step": dt / steps * 1e3,
+            "device_calls": calls, "rows_per_call": evals / max(1, calls),
+            "device_call_ms_per_step": t_dev[0] / steps * 1e3, "host_ms_per_step": (dt - t_dev[0]) / steps * 1e3,
+            "acceptance_fraction": float(np.mean(sampler.acceptance_fraction)), "finite_fraction": float(np.mean(np.isfinite(lp))),
+            "note": "starfish_amd.samplers.EnsembleSampler (Goodman-Weare stretch move, two half-ensembles per step) over "
+            "SpectrumModel.log_likelihood_batch with seven scipy.stats priors; the first run_mcmc call of the timed region also "
+            "evaluates its start (one call of all walkers): counted in evals and in the time"}
+
+
+def train_leg(w, iterations=25):
+    """SpectrumModel.train (spectrum_model.py:635-696): the reference's serial Nelder-Mead loop (B = 1 launches) against the
+    batched simplex (starfish_amd/_neldermead.py), same iterations -- wall clock of the whole call, host logic included."""
+    import scipy.stats as st
+
+    model = w.model
+    x0 = model.get_param_vector().copy()
+    out = {}
+    model.log_likelihood()
+    # (scipy's default simplex enlarges every coordinate by 5 %: T leaves the emulator grid, where the objective raises -- in
+    # the reference too; the prior keeps such vertices at -inf without a device call)
+    c = dict(zip(model.labels, x0))
+    priors = {"T": st.uniform(6000, 200), "vsini": st.uniform(0, 500)}
+    for key, kw in (("serial", dict(batch_simplex=False)), ("batched", {})):
+        model.set_param_vector(x0)
+        t0 = time.perf_counter()
+        s = model.train(priors, options=dict(maxiter=iterations), **kw)
+        out[key] = {"ms": (time.perf_counter() - t0) * 1e3, "nit": int(s.nit), "nfev": int(s.nfev),
+                    "device_calls": int(getattr(s, "nbatches", s.nfev))}
+    model.set_param_vector(x0)
+    out["speedup"] = out["serial"]["ms"] / out["batched"]["ms"]
+    out["note"] = (f"{iterations} Nelder-Mead iterations from the centre parameters (13 thawed), initial simplex included; same "
+                   "decisions in both (tests/test_gpu_train.py)")
+    return out
+
+
 def device_note():
     """Name and compute units of rank 0's GPU (boxes of the pool differ by a few per cent at the small batches)."""
     try:
@@ -888,10 +968,13 @@ def run(args, in_group, rank, local_rank, world, line):
         w2.release()
     default_run = (world == 1 and args.config == "cfg2" and not custom and args.grid == "loguniform"
                    and not args.no_extra_legs)
-    extra, proxy, proxy5, fill = None, None, None, None
+    extra, proxy, proxy5, fill, sampler, train = None, None, None, None, None, None
     if default_run:
         plist0, order0 = w.plist, w.order0
         base_ms_per_eval = t["ms_per_step"] / w.n_local
+        sampler = sampler_leg(w)
+        sampler["efficiency_vs_headline"] = sampler["evals_per_s"] / t["value"]
+        train = train_leg(w)
         fill = fill_leg(w)
         w.release()
         fill["unaligned"] = fill_unaligned_leg()
@@ -990,13 +1073,19 @@ def run(args, in_group, rank, local_rank, world, line):
         # their HIP-event intervals) is `panel_frac`.
         whole_tf = t["value"] * w.flops_eval / 1e12 / world
         alg_bytes_step = 16.0 * N * N * w.n_local  # C written once + read once
+        # (key order: the driver's record keeps the first ~24 scalars.  Schema since round 5: `frac` = whole path; the panel
+        # kernels' figure, `frac` of rounds 1-4, is `panel_frac`.)
         roof = {"bound": "mfma", "achieved": whole_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": whole_tf / FP64_MFMA_PEAK_TFLOPS, "whole_path_frac": whole_tf / FP64_MFMA_PEAK_TFLOPS,
-                "panel_frac": achieved / FP64_MFMA_PEAK_TFLOPS, "panel_achieved": achieved}
+                "frac": whole_tf / FP64_MFMA_PEAK_TFLOPS, "panel_frac": achieved / FP64_MFMA_PEAK_TFLOPS}
+        if sampler is not None:
+            roof["sampler_efficiency"] = sampler["efficiency_vs_headline"]
+            roof["sampler_host_ms_per_step"] = sampler["host_ms_per_step"]
+        if train is not None:
+            roof["train_batched_speedup"] = train["speedup"]
         if fill is not None:
-            roof["fill_frac"], roof["fill_gbs"] = fill["frac"], fill["achieved"]
+            roof["fill_frac"] = fill["frac"]
             if fill.get("unaligned"):
-                roof["fill_unaligned_frac"], roof["fill_unaligned_gbs"] = fill["unaligned"]["frac"], fill["unaligned"]["achieved"]
+                roof["fill_unaligned_frac"] = fill["unaligned"]["frac"]
         if proxy is not None:
             for row in proxy[1:]:
                 roof[f"b{row['batch']}_efficiency"] = row["per_eval_efficiency_vs_full_batch"]
@@ -1010,6 +1099,13 @@ def run(args, in_group, rank, local_rank, world, line):
                 roof[f"cfg5_b{row['batch']}_efficiency"] = row["per_eval_efficiency_vs_full_batch"]
         roof["traffic"] = traffic
         roof["traffic_ratio"] = traffic / alg_bytes_step if traffic else None  # counter bytes per step / 16 N^2 B
+        roof["schema"] = "frac = whole path (rounds 1-4: frac = panel kernels, now panel_frac)"
+        roof["whole_path_frac"] = whole_tf / FP64_MFMA_PEAK_TFLOPS
+        roof["panel_achieved"] = achieved
+        if fill is not None:
+            roof["fill_gbs"] = fill["achieved"]
+            if fill.get("unaligned"):
+                roof["fill_unaligned_gbs"] = fill["unaligned"]["achieved"]
         roof["traffic_is_this_code"] = traffic_same
         roof["sustained_clock_mhz"] = clock_mhz or None
         roof["peak_at_sustained_clock"] = FP64_MFMA_PEAK_TFLOPS * clock_mhz / 2400.0 if clock_mhz else None
@@ -1044,6 +1140,10 @@ def run(args, in_group, rank, local_rank, world, line):
                 "cfg5_rows": proxy5, "cfg5_note": "the same for cfg 5 (N = 16384): 32 / G walkers per GPU, 2 timed steps each"}
         if extra is not None:
             out["other_configs"] = extra
+        if sampler is not None:
+            out["sampler_step"] = sampler
+        if train is not None:
+            out["train"] = train
         if world == 1 and args.cpu_sample > 0 and plist0:
             out["cpu_baseline"] = cpu_baseline(order0, plist0, lnl_host, args)
         line.result(out)

@@ -1386,15 +1386,17 @@ __device__ __forceinline__ int sf_df_wait_r(const int* f1, int t1, const int* f2
                     }
                     const long long now = wall_clock64();
                     const long long waited = now - t0;
-                    const int pg = sf_df_load(abort_flag + 5);
-                    if (pg != pg0) {
-                        pg0 = pg;
-                        tp = now;
-                    } else if (now - tp > sf_df_stall_ticks(abort_flag)) {  // nothing completes any more: see SF_DF_STALL_TICKS
-                        const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
-                        sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3), SF_DF_ABORT_STALL, waited);
-                        ok = 0;
-                        break;
+                    if ((it & 255) == 0) {  // (every ~0.3 ms: one more L2 round trip in the polling loop -- measurable when taken every 32 polls)
+                        const int pg = sf_df_load(abort_flag + 5);
+                        if (pg != pg0) {
+                            pg0 = pg;
+                            tp = now;
+                        } else if (now - tp > sf_df_stall_ticks(abort_flag)) {  // nothing completes any more: see SF_DF_STALL_TICKS
+                            const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
+                            sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3), SF_DF_ABORT_STALL, waited);
+                            ok = 0;
+                            break;
+                        }
                     }
                     // (abort_flag[4]: the bound in units of 2^20 ticks when the host asked for another one -- tuning builds)
                     if (waited > SF_DF_TIMEOUT_TICKS && (abort_flag[4] == 0 || (waited >> 20) > abort_flag[4])) {
@@ -3471,6 +3473,7 @@ struct sf_df_args {
     int64_t sT;
     double* part;     // three regions of sf_split_region_tiles() tiles: rest partial sums by stage parity, front partial sums
     int* info;
+    int qbal;         // 1: with fewer matrices than queues the XCDs are dealt to the non-empty queues round-robin
     long long* diag;  // the process's abort record in host memory (sf_df_diag), or NULL
     long long* dbg;   // tuning builds: per workgroup {ticks waiting, ticks in task bodies, tasks, ticks by type} (100 MHz)
     int miss_claims;  // tuning builds (SF_DF_MISS_CLAIMS): 1 = the dispenser leaves chain / front tasks to the waits' rescue while its queues hold tasks; 2 = a claimed chain task is never run (forces the stall bound)
@@ -3489,6 +3492,11 @@ typedef const __attribute__((address_space(4))) sf_df_args sf_df_kargs;
 #define SF_DF_HELPER __forceinline__
 #else
 #define SF_DF_HELPER __attribute__((noinline))
+#endif
+#ifdef SF_EXP_NOPROGADD  // (timing experiment: what do the progress counter's adds cost?  The stall bound then fires on any long wait)
+#define SF_DF_PROGRESS()
+#else
+#define SF_DF_PROGRESS() sf_df_add(a.abort_flag + 5, 1)
 #endif
 #ifdef SF_TUNING
 #define SF_DF_MISS_CLAIMS(x) ((a.miss_claims & 1) && (x))
@@ -3548,7 +3556,11 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
     (void)a_in;
     // (workgroup b of a launch runs on XCD b % 8 -- observed, not promised; placement is a speed matter only here: any
     // workgroup may serve any queue)
+    // Fewer matrices than queues (batch < 8): the XCDs whose own queue is empty start on queue (XCD mod batch) instead of
+    // all falling through to queue 0 -- whose one matrix then had five XCDs (limited by its chain) while the others had one
+    // each (limited by throughput): N = 16384, 4 matrices 180 ms against 109 for the launch sequence.
     int qcur = (int)(blockIdx.x & (SF_DF_QUEUES - 1));
+    if (ap->qbal && ap->batch < SF_DF_QUEUES) qcur = qcur % ap->batch;
     int visited = 0;
     int kst = 0;  // stage hint: a workgroup draws the tasks of a queue in increasing order
     if (threadIdx.x == 0) {
@@ -3806,7 +3818,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 if (tid == 0) {
                     sf_df_release();
                     sf_df_set(a.done_row + (size_t)b * nt + slab, kp + 1);
-                    sf_df_add(a.abort_flag + 5, 1);  // (progress of the launch: see SF_DF_STALL_TICKS)
+                    SF_DF_PROGRESS();  // (progress of the launch: see SF_DF_STALL_TICKS)
                 }
             }
             if (ok && type == T_C) {
@@ -3832,7 +3844,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 if (tid == 0) {
                     sf_df_release();
                     sf_df_set(a.done_D + b, k + 1);
-                    sf_df_add(a.abort_flag + 5, 1);
+                    SF_DF_PROGRESS();
                 }
             }
             if (type == T_C) __builtin_amdgcn_s_setprio(0);
@@ -3945,7 +3957,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                     sf_df_set(rowflag, k + 1);
                     if (type == T_RR) sf_df_add(sdone + k, 1);
                 }
-                sf_df_add(a.abort_flag + 5, 1);
+                SF_DF_PROGRESS();
             }
         }
         if (!ok) continue;  // (timed out: the dispenser sees the abort flag and flags every matrix)
@@ -4136,6 +4148,8 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     a.part = part;
     a.info = info;
     a.diag = sf_df_diag();
+    static const int qbal_env = SF_TUNE_INT("SF_DF_QBAL", 1);
+    a.qbal = qbal_env;
 #ifdef SF_TUNING
     if (SF_TUNE_FLAG("SF_DF_VERBOSE")) a.dbg = (long long*)(flags + ((nflags - ndbg + 1) & ~(size_t)1));
     static const char* trace_file = SF_TUNE_STR("SF_DF_TRACE_FILE");  // every task's {what, claimed, body start, end} as text
@@ -4147,7 +4161,11 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
 #endif
 
     // ---- the task tables: one per queue size (ceil and floor of batch / 8)
-    static const int cap = SF_TUNE_INT("SF_DF_CAP", SF_CHIP_WGS / SF_DF_QUEUES);  // workgroup slots of one XCD
+    static const int cap_env = SF_TUNE_INT("SF_DF_CAP", 0);
+    // workgroup slots a queue can count on: those of one XCD -- of 8 / batch XCDs when there are fewer matrices than queues
+    // (bounded by the partial-sum tiles a queue owns)
+    const int cap = cap_env > 0 ? cap_env
+                                : (a.qbal && batch < SF_DF_QUEUES ? std::min<int>(SF_DF_QTILES, SF_CHIP_WGS / batch) : SF_CHIP_WGS / SF_DF_QUEUES);
     // front partial-sum tasks per queue, panel and front slab (64 / 32 / 16 / 8 with a one-slab front: B = 32 14.9 / 14.8 / 14.55 /
     // 14.45 ms, B = 48 20.8 / 20.2 / 20.2 / 20.6)
     static const int pt_tasks = SF_TUNE_INT("SF_DF_PT_TASKS", 16);
@@ -4346,7 +4364,11 @@ static bool sf_potrf_dataflow_auto(int n, int batch) {
     // (the measured dispatch rule counts panels conservatively, with 64 virtual rows: at N = 4096 it is 33 x batch <= 2048,
     // i.e. up to 62 matrices)
     const int nt = (n + 64 + GT - 1) / GT;
-    return sf_potrf_dataflow_fits(n, batch) && (long long)batch * nt <= lim && batch <= 128;
+    // (... and stops at N = 8192: the kernel FITS up to N = 16384 -- forced sequence 4, tests -- but was only ever measured to
+    // win up to 65 panels; at N = 16384 the tasks are milliseconds long and the launch sequences keep the chip as full:
+    // profiles/r06_a_dataflow_n16384.txt)
+    static const int nt_max = SF_TUNE_INT("SF_DF_NT_MAX", 65);
+    return sf_potrf_dataflow_fits(n, batch) && (long long)batch * nt <= lim && batch <= 128 && nt <= nt_max;
 }
 int sf_potrf_front_pad(int n, int batch) {
     static const bool off = SF_TUNE_FLAG("SF_NO_FRONT_PAD");  // tuning aid: A/B of the shifted frame

@@ -176,3 +176,92 @@ def test_cfg4_order_major_split_vs_reference_goldens(tmp_path, world):
         assert owned[r] == [o for o, _, _ in order_major_slices(n_orders, B, lo, hi)]
         assert owned[r] == list(range(owned[r][0], owned[r][-1] + 1)) and len(owned[r]) <= -(-n_orders // world) + 1
     assert owned[0][0] == 0 and owned[-1][-1] == n_orders - 1
+
+
+# ------------------------------------------------------------- eight ranks, each with the device to itself in turn
+def _turns_worker(rank, world, port, out_dir):
+    """cfg 2 split eight ways (16 walkers per rank) with the PER-GPU DEFAULT path: the persistent-kernel Cholesky stays on.
+    Eight GPUs give every rank a device of its own; the one GPU of the test box is handed round instead -- an exclusive file
+    lock around every device call, so that no two processes ever have kernels in flight together (the eight contexts and
+    their memory stay resident side by side: that much of a shared device remains)."""
+    import fcntl
+    import json
+    import warnings
+
+    import torch
+    import torch.distributed as dist
+
+    from starfish_amd import _device as D, _lib
+    from starfish_amd.parallel import gather_host, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        lib = _lib.require_gpu()
+        assert lib.sf_persistent_potrf(-1) == 1  # the library's own choice, not switched off
+        o = synth.make_order(N=4096)
+        P = synth.walker_ball(o, B=128)
+        lo, hi = shard_range(len(P), rank, world)
+        lock = open(os.path.join(out_dir, "device.lock"), "w")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fcntl.flock(lock, fcntl.LOCK_EX)  # ---- this rank's turn: build (init-time device work) + evaluate + synchronise
+            try:
+                model = synth.build_model(o)
+                before = D.persistent_status(lib)
+                local, info = model.log_likelihood_batch(P[lo:hi], return_info=True)
+                again = model.log_likelihood_batch(P[lo:hi])
+                torch.cuda.synchronize()
+                after = D.persistent_status(lib)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+        assert (info == 0).all()
+        np.testing.assert_array_equal(local, again)
+        full = gather_host(local, len(P))  # host gather (gloo), no data-path collective
+        np.save(os.path.join(out_dir, f"turns{rank}.npy"), full)
+        with open(os.path.join(out_dir, f"turns{rank}.json"), "w") as fh:
+            json.dump(dict(launches=after["launches"] - before["launches"], aborted=after["aborted_launches"],
+                           enabled=lib.sf_persistent_potrf(-1), warned=[str(x.message) for x in w]), fh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_take_turns_on_the_device_with_the_persistent_kernel_on(tmp_path):
+    """the shared-device rehearsals above switch the persistent kernel off, so the path eight GPUs would run --
+    k_potrf_dataflow on 16 matrices per rank -- had never run inside a multi-process job.  Here it does (two persistent
+    launches per rank, none aborted, no warning); the gathered batch equals what ONE process computes slice by slice bit for
+    bit, the full batch of 128 (another launch sequence: panel pairs) to rounding, and the reference's values."""
+    import json
+    import time
+
+    from conftest import load_golden
+    from starfish_amd.parallel import shard_range
+
+    world = 8
+    ctx = mp.spawn(_turns_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+    deadline = time.time() + 600
+    done = False
+    while time.time() < deadline:
+        done = ctx.join(timeout=5)
+        if done:
+            break
+    if not done:
+        for p in ctx.processes:
+            p.terminate()
+        pytest.fail("the 8 GPU worker processes did not finish within 600 s")
+    o = synth.make_order(N=4096)
+    P = synth.walker_ball(o, B=128)
+    model = synth.build_model(o)
+    want_slices = np.concatenate([model.log_likelihood_batch(P[slice(*shard_range(128, r, world))]) for r in range(world)])
+    want_full = model.log_likelihood_batch(P)
+    g2, gf = load_golden("model_cfg2.npz"), load_golden("model_fullbatch.npz")
+    for r in range(world):
+        got = np.load(tmp_path / f"turns{r}.npy")
+        np.testing.assert_array_equal(got, want_slices)           # same launch shape (16 matrices): same bits
+        np.testing.assert_allclose(got, want_full, rtol=1e-11)    # the full batch takes the panel-pair sequence
+        assert np.all(np.abs(got[:8] - g2["n4096_batch_lnl"]) <= 1e-8 * np.abs(g2["n4096_batch_lnl"]) + 1e-8)
+        assert abs(got[127] - gf["cfg2_lnl127"][0]) <= 1e-8 * abs(gf["cfg2_lnl127"][0]) + 1e-8
+        rec = json.load(open(tmp_path / f"turns{r}.json"))
+        assert rec["launches"] == 2 and rec["aborted"] == 0 and rec["enabled"] == 1 and rec["warned"] == [], rec

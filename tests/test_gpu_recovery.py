@@ -252,7 +252,7 @@ def test_a_launch_whose_claimed_task_never_runs_is_given_up_within_the_stall_bou
     st = got["status"]
     assert st["aborted_launches"] == 1 and st["reason"] == 2, st   # no task completed for 25 ms
     assert st["workgroups_started"] == st["grid"] > 0, st          # (an exclusive box: the whole grid was resident)
-    assert 0 < st["tasks_completed"] < 200, st
+    assert st["tasks_completed"] > 0, st                          # (the other three matrices ran to their ends)
     assert got["seconds"] < 0.5, got["seconds"]                    # 25-35 ms of stall + the launch, not 4 s
     assert got["minfo"] == [0] * 16 and np.isfinite(got["lnl"]).all()
     assert len(got["warned"]) == 1 and "no task of the launch completed for 25 ms" in got["warned"][0], got["warned"]

@@ -13,7 +13,7 @@ from starfish_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-PRIORS = {"global_cov:log_amp": st.norm(-9, 5), "vsini": st.uniform(0, 500), "T": st.uniform(5990, 220)}
+PRIORS = {"global_cov:log_amp": st.norm(-9, 5), "vsini": st.uniform(0, 500), "T": st.uniform(6000, 200)}
 
 
 def _model(N=256, m=4, seed=5):
@@ -37,7 +37,7 @@ def test_batched_train_follows_scipys_iterates_on_the_small_golden_case():
     model = _model()
     got = model.train(PRIORS, options=opts)
     assert (got.nit, got.nfev, got.status) == (want.nit, want.nfev, want.status)
-    assert len(got.allvecs) == len(want.allvecs) == want.nit + 1
+    assert len(got.allvecs) == len(want.allvecs) == want.nit  # (scipy counts the initial simplex as iteration 1)
     for a, b in zip(got.allvecs, want.allvecs):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(got.final_simplex[1], want.final_simplex[1], rtol=1e-10)
@@ -81,11 +81,13 @@ def test_batched_simplex_is_faster_per_iteration_than_the_serial_loop_at_n4096()
         m.log_likelihood()  # (contexts, workspaces, first launches)
         m.log_likelihood_batch(np.tile(m.get_param_vector(), (14, 1)))
     opts = dict(maxiter=12)
+    # (scipy's default simplex enlarges every coordinate by 5 %: T = 6050 K -> 6352 K leaves the emulator grid, where the
+    # objective raises -- in the reference too; a prior keeps such vertices at -inf without a device call)
     t0 = time.perf_counter()
-    s1 = a.train(batch_simplex=False, options=opts)
+    s1 = a.train(PRIORS, batch_simplex=False, options=opts)
     t_serial = time.perf_counter() - t0
     t0 = time.perf_counter()
-    s2 = b.train(options=opts)
+    s2 = b.train(PRIORS, options=opts)
     t_batched = time.perf_counter() - t0
     assert s1.nit == s2.nit == 12 and s1.nfev == s2.nfev
     np.testing.assert_allclose(s2.x, s1.x, rtol=1e-9)

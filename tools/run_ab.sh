@@ -13,7 +13,7 @@ for r in $(seq 1 $ROUNDS); do
   for c in "${CS[@]}"; do
     for t in $TAGS; do
       echo "== round $r tag $t case $c" >> $OUT
-      SF_LIB_PATH=$PWD/starfish_amd/libstarfish_amd_$t.so timeout 300 python tools/bench_potrf.py $c 2>&1 | grep -E "potrf [0-9]|during|max .L" >> $OUT
+      SF_ALLOW_OLD_LIB=1 SF_LIB_PATH=$PWD/starfish_amd/libstarfish_amd_$t.so timeout 300 python tools/bench_potrf.py $c 2>&1 | grep -E "potrf [0-9]|during|max .L" >> $OUT
     done
   done
 done

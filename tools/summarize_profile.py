@@ -24,32 +24,76 @@ def find(pattern):
     return hits[0] if hits else None
 
 
+def bench_line(name):
+    """Last JSON line a bench.py run of the profiling script printed (bench_under_rocprof.json / bench_plain.json)."""
+    try:
+        with open(os.path.join(src, name)) as fh:
+            return json.loads([ln for ln in fh if ln.startswith("{")][-1])
+    except Exception:
+        return {}
+
+
+def interval_union(iv):
+    iv = sorted(iv)
+    if not iv:
+        return 0
+    uni, lo, hi = 0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a <= hi:
+            hi = max(hi, b)
+        else:
+            uni += hi - lo
+            lo, hi = a, b
+    return uni + hi - lo
+
+
 stats_f = find("stats/**/*kernel_stats.csv")
 stats = list(csv.DictReader(open(stats_f))) if stats_f else []
-with open(dst + "_kernel_stats.csv", "w") as fh:
-    fh.write("kernel,calls,total_ms,avg_us,percent\n")
-    for r in stats:
-        fh.write(f"{short(r['Name'])},{r['Calls']},{int(r['TotalDurationNs'])/1e6:.3f},"
-                 f"{float(r['AverageNs'])/1e3:.2f},{float(r['Percentage']):.2f}\n")
 
-# union of the (overlapping, multi-stream) panel-kernel launch intervals per bench step, from the kernel trace
+# union of the (overlapping, multi-stream) launch intervals of a kernel FAMILY, from the kernel trace of the same run:
+# per-kernel total_ms sums launches that run side by side on three streams (cfg 2: 772 ms summed, 321 ms elapsed), so
+# the per-kernel rows alone overstate the time; the `_union:` rows below are what a roofline fraction is computed from
 trace_f = find("stats/**/*kernel_trace.csv")
-union = None
+union, union_rows = None, []
 if trace_f:
     tr = sorted(csv.DictReader(open(trace_f)), key=lambda r: int(r["Start_Timestamp"]))
     nsteps = max(1, sum(1 for r in tr if r["Kernel_Name"].startswith("k_finish")))
     iv = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in tr if any(p in r["Kernel_Name"] for p in PANEL)]
+    under = bench_line("bench_under_rocprof.json")
+    roof = under.get("roofline") or {}
     if iv:
-        uni, lo, hi = 0, iv[0][0], iv[0][1]
-        for a, b in iv[1:]:
-            if a <= hi:
-                hi = max(hi, b)
-            else:
-                uni += hi - lo
-                lo, hi = a, b
-        uni += hi - lo
+        uni = interval_union(iv)
         union = {"k_finish_calls": nsteps, "launches": len(iv), "union_ms_total": uni / 1e6,
                  "sum_ms_total": sum(b - a for a, b in iv) / 1e6}
+        # algorithmic flops of the panel launches of ONE step, as the library counts them (bench line of the same run)
+        gf = None
+        if roof.get("algorithmic_flops_per_launch") and roof.get("launches") and roof.get("profiled_steps"):
+            gf = roof["algorithmic_flops_per_launch"] * roof["launches"] / roof["profiled_steps"] / 1e9
+        ms_step = uni / 1e6 / nsteps
+        union_rows.append(("_union:panel kernels (k_chol_panel* + k_potrf_dataflow + k_gemm_nt)", len(iv), uni / 1e6, nsteps,
+                           ms_step, gf, "GFLOP", gf / ms_step if gf else None, "TFLOP/s", 78.6))
+    if under.get("ms_per_step") and under.get("whole_path_tflops"):
+        gf = under["whole_path_tflops"] * under["ms_per_step"]  # TFLOP/s x ms = GFLOP per step (all stages, all units)
+        union_rows.append(("_whole_step:bench line of this run (under rocprofv3)", "", under["ms_per_step"] * under.get("steps", 1),
+                           under.get("steps", 1), under["ms_per_step"], gf, "GFLOP", under["whole_path_tflops"], "TFLOP/s", 78.6))
+    fiv = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in tr if "k_fill_dense" in r["Kernel_Name"]]
+    fill = (under.get("fill") or {})
+    if fiv and fill.get("algorithmic_bytes_per_launch"):
+        nfill = max(1, sum(1 for r in tr if "k_fill_dense_plain" in r["Kernel_Name"]))
+        uni = interval_union(fiv)
+        gb = fill["algorithmic_bytes_per_launch"] / 1e9
+        ms_step = uni / 1e6 / nfill
+        union_rows.append(("_union:dense fill (k_fill_dense_plain + k_fill_dense_band, two streams)", len(fiv), uni / 1e6, nfill,
+                           ms_step, gb, "GB", gb / ms_step * 1e3, "GB/s", 8000.0))
+with open(dst + "_kernel_stats.csv", "w") as fh:
+    fh.write("kernel,calls,total_ms,avg_us,percent,steps,ms_per_step,algorithmic_per_step,algorithmic_unit,rate,rate_unit,frac_of_peak\n")
+    for r in stats:
+        fh.write(f"{short(r['Name'])},{r['Calls']},{int(r['TotalDurationNs'])/1e6:.3f},"
+                 f"{float(r['AverageNs'])/1e3:.2f},{float(r['Percentage']):.2f},,,,,,,\n")
+    # (total_ms of a `_union:` row = elapsed time covered by the family's launches, overlaps counted once)
+    for name, calls_u, tot, steps_u, ms_step, alg, unit, rate, runit, peak in union_rows:
+        fh.write(f"{name},{calls_u},{tot:.3f},,,{steps_u},{ms_step:.4f},{'' if alg is None else f'{alg:.3f}'},{unit},"
+                 f"{'' if rate is None else f'{rate:.3f}'},{runit},{'' if rate is None else f'{rate / peak:.4f}'}\n")
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(int)
