@@ -1360,6 +1360,39 @@ __device__ __forceinline__ long long sf_df_stall_ticks(const int* abort_flag) {
 struct sf_df_no_rescue {
     __device__ __forceinline__ bool operator()() const { return false; }
 };
+// The rare part of a wait (every 32nd poll), out of line: the waits are inlined at a dozen sites of a kernel whose task loop is
+// 100 KB of code -- with the abort record and the stall bound inlined as well every site grew, and launches of 32-64 matrices
+// ran 1.2 % slower (same-box A/B, both orders: profiles/r06_b_dataflow_wait_code_size_ab.txt).
+// Returns 0: keep polling; 1: give up (the launch is being aborted, by somebody else or by this call); 2: keep polling, and
+// the wait has lasted long enough for the caller to look for an unclaimed chain task (SF_DF_RESCUE_TICKS).
+struct sf_df_watch {
+    long long t0, tp;  // start of the wait; when the launch's progress counter last moved, as seen from this wait
+    int pg0;
+};
+__device__ __attribute__((noinline)) int sf_df_wait_slow(sf_df_watch& w, int* abort_flag, const int* f1, int t1, const int* f2, int t2,
+                                                         const int* f3, int t3, const bool look_at_progress) {
+    if (sf_df_load(abort_flag) != 0) return 1;
+    const long long now = wall_clock64();
+    const long long waited = now - w.t0;
+    int reason = 0;
+    if (look_at_progress) {  // (every ~0.3 ms: one more L2 round trip in the polling loop)
+        const int pg = sf_df_load(abort_flag + 5);
+        if (pg != w.pg0) {
+            w.pg0 = pg;
+            w.tp = now;
+        } else if (now - w.tp > sf_df_stall_ticks(abort_flag)) {  // nothing completes any more: see SF_DF_STALL_TICKS
+            reason = SF_DF_ABORT_STALL;
+        }
+    }
+    // (abort_flag[4]: the bound in units of 2^20 ticks when the host asked for another one -- tuning builds)
+    if (!reason && waited > SF_DF_TIMEOUT_TICKS && (abort_flag[4] == 0 || (waited >> 20) > abort_flag[4])) reason = SF_DF_ABORT_TIMEOUT;
+    if (reason) {
+        const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
+        sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3), reason, waited);
+        return 1;
+    }
+    return waited > SF_DF_RESCUE_TICKS ? 2 : 0;
+}
 template <class RESCUE>
 __device__ __forceinline__ int sf_df_wait_r(const int* f1, int t1, const int* f2, int t2, const int* f3, int t3,
                                             const int* probe, int tprobe, bool* probe_ok, int* abort_flag, const int tid,
@@ -1372,40 +1405,20 @@ __device__ __forceinline__ int sf_df_wait_r(const int* f1, int t1, const int* f2
             return (!f1 || sf_df_load(f1) >= t1) && (!f2 || sf_df_load(f2) >= t2) && (!f3 || sf_df_load(f3) >= t3);
         };
         if (!ready()) {
-            const long long t0 = wall_clock64();
-            long long tp = t0;                       // when the launch's progress counter last moved, as seen from this wait
-            int pg0 = sf_df_load(abort_flag + 5);
+            sf_df_watch w;
+            w.t0 = w.tp = wall_clock64();
+            w.pg0 = sf_df_load(abort_flag + 5);
             unsigned it = 0;
             for (;;) {
                 __builtin_amdgcn_s_sleep(4);
                 if (ready()) break;
                 if ((++it & 31) == 0) {
-                    if (sf_df_load(abort_flag) != 0) {
+                    const int r = sf_df_wait_slow(w, abort_flag, f1, t1, f2, t2, f3, t3, (it & 255) == 0);
+                    if (r == 1) {
                         ok = 0;
                         break;
                     }
-                    const long long now = wall_clock64();
-                    const long long waited = now - t0;
-                    if ((it & 255) == 0) {  // (every ~0.3 ms: one more L2 round trip in the polling loop -- measurable when taken every 32 polls)
-                        const int pg = sf_df_load(abort_flag + 5);
-                        if (pg != pg0) {
-                            pg0 = pg;
-                            tp = now;
-                        } else if (now - tp > sf_df_stall_ticks(abort_flag)) {  // nothing completes any more: see SF_DF_STALL_TICKS
-                            const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
-                            sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3), SF_DF_ABORT_STALL, waited);
-                            ok = 0;
-                            break;
-                        }
-                    }
-                    // (abort_flag[4]: the bound in units of 2^20 ticks when the host asked for another one -- tuning builds)
-                    if (waited > SF_DF_TIMEOUT_TICKS && (abort_flag[4] == 0 || (waited >> 20) > abort_flag[4])) {
-                        const bool m1 = f1 && sf_df_load(f1) < t1, m2 = f2 && sf_df_load(f2) < t2;
-                        sf_df_report(abort_flag, m1 ? f1 : (m2 ? f2 : f3), m1 ? t1 : (m2 ? t2 : t3), SF_DF_ABORT_TIMEOUT, waited);
-                        ok = 0;
-                        break;
-                    }
-                    if (can_rescue && waited > SF_DF_RESCUE_TICKS && rescue()) {
+                    if (r == 2 && can_rescue && rescue()) {
                         ok = SF_DF_DEFERRED;
                         break;
                     }
@@ -1448,6 +1461,8 @@ __device__ __forceinline__ void sf_df_add(int* flag, int value) {
 // K slabs [g.ktail, panel) accumulated by this workgroup after the partial sums (dataflow sequence: the chain's step).
 // `id` = tile (MODE 1: tile * ksplit + split) index; sm / red: 4 * GT * GLD + 2 * GT doubles of LDS.
 // (GA: `const sf_panel_args`, or the same in the constant address space -- the kernel arguments of k_potrf_dataflow)
+// (MODE 3 with ksplit = 0, ktail = 0 is MODE 0, and with ktail = the panel's K slab count it is MODE 2: k_potrf_dataflow runs
+// every task type but the partial sums through ONE inlined copy of <3> -- see there.)
 template <bool RHS, int MODE, class GA>
 __device__ __forceinline__ void sf_panel_body(GA& g, const sf_panel_task& tk, const int id, double* __restrict__ sm,
                                               double (*red)[GT], const int tid) {
@@ -3556,11 +3571,28 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
     (void)a_in;
     // (workgroup b of a launch runs on XCD b % 8 -- observed, not promised; placement is a speed matter only here: any
     // workgroup may serve any queue)
-    // Fewer matrices than queues (batch < 8): the XCDs whose own queue is empty start on queue (XCD mod batch) instead of
-    // all falling through to queue 0 -- whose one matrix then had five XCDs (limited by its chain) while the others had one
-    // each (limited by throughput): N = 16384, 4 matrices 180 ms against 109 for the launch sequence.
+    // Workgroups are dealt to the queues in proportion to the MATRICES a queue holds (round 6): every matrix gets 512 / batch
+    // workgroup slots.  A batch that is not a multiple of 8 leaves the first batch % 8 queues one matrix more than the others
+    // (with fewer than 8 matrices: the others empty): the XCDs of the smaller queues keep round(matrices x 512 / batch) of
+    // their 64 workgroups and send the rest to the larger queues, round-robin.  Before, such workgroups only moved on when
+    // their own queue was exhausted -- with an empty own queue all of them to queue 0, whose one matrix then had five XCDs
+    // (limited by its chain) while the others had one each (limited by throughput): N = 16384, 4 matrices 180 ms against 109
+    // for the launch sequence; 12 matrices cost what 16 cost.  (8 % batch == 0: whole XCDs, the matrix's operands stay in
+    // one L2.)
     int qcur = (int)(blockIdx.x & (SF_DF_QUEUES - 1));
-    if (ap->qbal && ap->batch < SF_DF_QUEUES) qcur = qcur % ap->batch;
+    {
+        const int nb = ap->batch, big = nb % SF_DF_QUEUES;  // queues 0 .. big - 1 hold one matrix more
+        if (ap->qbal && big != 0) {
+            if (nb < SF_DF_QUEUES && SF_DF_QUEUES % nb == 0) {
+                qcur = qcur % nb;
+            } else {
+                const int mine = (nb - qcur + SF_DF_QUEUES - 1) / SF_DF_QUEUES;  // matrices of this XCD's own queue
+                const int slot = (int)(blockIdx.x >> 3);
+                const int keep = (int)(((long long)mine * gridDim.x + nb / 2) / nb);  // its share of the grid's workgroups
+                if (qcur >= big && slot >= keep) qcur = (slot - keep + qcur) % big;
+            }
+        }
+    }
     int visited = 0;
     int kst = 0;  // stage hint: a workgroup draws the tasks of a queue in increasing order
     if (threadIdx.x == 0) {
@@ -3765,6 +3797,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
         };
         int* fcnt = a.fp_cnt + 2 * SF_DF_FRONT_MAX * b;
         bool ok = true;
+        int mode = 3, bid = b;  // which body runs: 1 = partial sums (bid = b S + split), 3 = everything else
         if (type == T_C || type == T_FR) {
             // the step of the front slab k+d (chain: of slab k for panel kp = k - 1) for panel kp: partial sums, K tail, epilogue
             const int kp = type == T_C ? k - 1 : k;
@@ -3774,10 +3807,9 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 q.Sout = a.T;                   // (g.sS = a.sT, g.ldS = SF_LDT)
             }
             if (kp < 0) {
-                // start of the factorisation: diagonal tile 0 goes to the scratch unchanged (pw = 0)
+                // start of the factorisation: diagonal tile 0 goes to the scratch unchanged (pw = 0, mode 0)
                 if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 __syncthreads();
-                sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
             } else {
                 const sf_df_stage stp = sf_df_stage_of(a.st[vb][kp > 0 ? kp - 1 : 0]);  // (FP(., kp, ., .) belongs to stage kp - 1)
                 const int St = kp >= 1 ? stp.St : 0;
@@ -3810,44 +3842,7 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
 #ifdef SF_TUNING
                 if (a.dbg && b == 0 && type == T_C && k < 64) q.stamps = a.dbg + 16 * SF_CHIP_WGS + 16 * 64 + 8 * k;
 #endif
-                SF_DF_MARK();
-                if (ok) sf_panel_body<RHS, 3>(g, q, b, sm, red, tid);
             }
-            if (ok && type == T_FR) {
-                __syncthreads();
-                if (tid == 0) {
-                    sf_df_release();
-                    sf_df_set(a.done_row + (size_t)b * nt + slab, kp + 1);
-                    SF_DF_PROGRESS();  // (progress of the launch: see SF_DF_STALL_TICKS)
-                }
-            }
-            if (ok && type == T_C) {
-                __syncthreads();
-#ifdef SF_TUNING
-                dbg_top = wall_clock64();
-#endif
-                if (tid == 0) {  // the parked tile must be re-read through the L2 (k = 0: nothing was published from the body)
-                    if (k == 0) {
-                        sf_df_release();
-                        sf_df_set(a.done_top + b, k);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                __syncthreads();
-                const int k0 = k * GT;
-                const int pw = min(GT, n - k0);
-                sf_diag_lds_body(a.T, a.sT, pw, a.info, k0 - fp, g.rhs ? g.rhs + k0 : nullptr, g.ldr,
-                                 g.C + (int64_t)k0 * g.lda + k0, g.lda, g.sC, Wof(k), a.sT, k == 0 ? fp : 0, b, dsm, tid);
-                __syncthreads();
-                if (tid == 0) {
-                    sf_df_release();
-                    sf_df_set(a.done_D + b, k + 1);
-                    SF_DF_PROGRESS();
-                }
-            }
-            if (type == T_C) __builtin_amdgcn_s_setprio(0);
         } else {
             // ---- queued tasks: ONE wait site for the four types (it carries the chain rescue, see sf_df_wait_r)
             const int k0 = k * GT;
@@ -3928,22 +3923,72 @@ __global__ __launch_bounds__(512, 4) void k_potrf_dataflow(const sf_df_args a_in
                 continue;
             }
             ok = wr == 1;
-            SF_DF_MARK();
-            if (ok) {
-                if (type == T_FP) {
-                    sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
-                } else if (type == T_R) {
-                    if (!dready) {
-                        q.wflag = a.done_D + b;
-                        q.wval = k + 1;
-                    }
-                    sf_panel_body<RHS, 0>(g, q, b, sm, red, tid);
-                } else if (type == T_RP) {
-                    sf_panel_body<RHS, 1>(g, q, b * S + sp, sm, red, tid);
-                } else {
-                    sf_panel_body<RHS, 2>(g, q, b, sm, red, tid);
+            if (type == T_FP || type == T_RP) {
+                mode = 1;
+                bid = b * S + sp;
+            } else if (type == T_R) {  // the whole step: mode 3 without partial sums, K loop from the start
+                q.ksplit = 0;
+                q.ktail = 0;
+                if (!dready) {
+                    q.wflag = a.done_D + b;
+                    q.wval = k + 1;
+                }
+            } else {  // T_RR: mode 3 with an empty K loop (the partial sums cover all of it)
+                q.ktail = k0 / GK;
+            }
+        }
+        // ---- the bodies: TWO inlined copies for the six task types -- the partial sums (FP, RP), and <3> for everything else: the
+        // chain / front step as it is, the whole step (R) as <3> without partial sums, the reduce (RR) as <3> with an empty K
+        // loop, the copy of diagonal tile 0 as <3> with pw = 0.  With one copy per type the kernel was 113 KB of code; the
+        // instruction cache is 64 KB and shared by two CUs whose four workgroups run different task types (now: ~60 KB).
+        SF_DF_MARK();
+        if (ok) {
+            if (mode == 1)
+                sf_panel_body<RHS, 1>(g, q, bid, sm, red, tid);
+            else
+                sf_panel_body<RHS, 3>(g, q, bid, sm, red, tid);
+        }
+        if (type == T_C || type == T_FR) {
+            const int kp = type == T_C ? k - 1 : k;
+            const int slab = kp + d;
+            if (ok && type == T_FR) {
+                __syncthreads();
+                if (tid == 0) {
+                    sf_df_release();
+                    sf_df_set(a.done_row + (size_t)b * nt + slab, kp + 1);
+                    SF_DF_PROGRESS();  // (progress of the launch: see SF_DF_STALL_TICKS)
                 }
             }
+            if (ok && type == T_C) {
+                __syncthreads();
+#ifdef SF_TUNING
+                dbg_top = wall_clock64();
+#endif
+                if (tid == 0) {  // the parked tile must be re-read through the L2 (k = 0: nothing was published from the body)
+                    if (k == 0) {
+                        sf_df_release();
+                        sf_df_set(a.done_top + b, k);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const int k0 = k * GT;
+                const int pw = min(GT, n - k0);
+                sf_diag_lds_body(a.T, a.sT, pw, a.info, k0 - fp, g.rhs ? g.rhs + k0 : nullptr, g.ldr,
+                                 g.C + (int64_t)k0 * g.lda + k0, g.lda, g.sC, Wof(k), a.sT, k == 0 ? fp : 0, b, dsm, tid);
+                __syncthreads();
+                if (tid == 0) {
+                    sf_df_release();
+                    sf_df_set(a.done_D + b, k + 1);
+                    SF_DF_PROGRESS();
+                }
+            }
+            if (type == T_C) __builtin_amdgcn_s_setprio(0);
+        } else {
+            int* rowflag = a.done_row + (size_t)b * nt + i;
+            int* sdone = a.stage_done + (size_t)qcur * nt;
             // (a workgroup that left the body on a timed-out wait finds the abort flag at the dispenser)
             __syncthreads();
             if (ok && tid == 0) {
@@ -4164,8 +4209,11 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
     static const int cap_env = SF_TUNE_INT("SF_DF_CAP", 0);
     // workgroup slots a queue can count on: those of one XCD -- of 8 / batch XCDs when there are fewer matrices than queues
     // (bounded by the partial-sum tiles a queue owns)
-    const int cap = cap_env > 0 ? cap_env
-                                : (a.qbal && batch < SF_DF_QUEUES ? std::min<int>(SF_DF_QTILES, SF_CHIP_WGS / batch) : SF_CHIP_WGS / SF_DF_QUEUES);
+    auto cap_of = [&](int Bq) {
+        if (cap_env > 0) return cap_env;
+        if (!a.qbal || batch % SF_DF_QUEUES == 0) return SF_CHIP_WGS / SF_DF_QUEUES;
+        return std::max(16, std::min<int>(SF_DF_QTILES, (int)((long long)Bq * SF_CHIP_WGS / batch)));
+    };
     // front partial-sum tasks per queue, panel and front slab (64 / 32 / 16 / 8 with a one-slab front: B = 32 14.9 / 14.8 / 14.55 /
     // 14.45 ms, B = 48 20.8 / 20.2 / 20.2 / 20.6)
     static const int pt_tasks = SF_TUNE_INT("SF_DF_PT_TASKS", 16);
@@ -4181,6 +4229,7 @@ static int sf_launch_potrf_v4(double* A, int n, int lda, int64_t stride, int bat
             a.ntasks[v] = v == 1 ? a.ntasks[0] : 0;
             continue;
         }
+        const int cap = cap_of(B);
         int off = 0, thr_pt[2] = {0, 0}, thr_rp = 0, last_split[2] = {-1, -1};
         bool seen[2][SF_DF_FRONT_MAX] = {};
         for (int k = 0; k + 1 < nt; ++k) {
