@@ -356,8 +356,9 @@ int sf_persistent_potrf_status(long long* h_out8);
  * mode -1 = choose by batch and matrix size (default), 0 = always fused, 1 = always unfused, 2 = always wide,
  * 3 = wide for the first half of the panels, then fused (test aid: exercises the hand-over between the two),
  * 4 = dataflow: the whole factorisation as ONE persistent launch whose workgroups draw tasks and wait on exactly the tasks
- * they depend on (the default while batch x 128-column panels <= 2048 and batch <= 128; matrices of more than 128 panels
- * -- N > 16384 -- take the fused sequence instead).
+ * they depend on (the default while batch x 128-column panels <= 2048, batch <= 128 and N <= 8192 -- every scalar evaluation,
+ * the half-ensembles of a sampler, the per-GPU batches of a strong split; forced, it takes up to 128 panels, N = 16384, beyond
+ * that the fused sequence runs instead).
  * The fused and wide sequences factorise matrices of 64 mod 128 rows in a frame shifted by 64 virtual identity rows
  * (addressing only: nothing moves in memory, the caller's layout and the pivot index reported in d_info are unchanged).
  * Same results to rounding. */

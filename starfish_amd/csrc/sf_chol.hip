@@ -4410,9 +4410,9 @@ static bool sf_potrf_dataflow_fits(int n, int batch) {
 }
 static bool sf_potrf_dataflow_auto(int n, int batch) {
     static const int lim = SF_TUNE_INT("SF_DF_BELOW", 2048);
-    // (the measured dispatch rule counts panels conservatively, with 64 virtual rows: at N = 4096 it is 33 x batch <= 2048,
-    // i.e. up to 62 matrices)
-    const int nt = (n + 64 + GT - 1) / GT;
+    // (round 6: the panel count is the true one -- N = 4096: up to 64 matrices, the half-ensemble of a 128-walker sampler; same
+    // box, persistent kernel / fused sequence there: 25.5 / 26.0 ms.  Rounds 4-5 counted 64 virtual rows more: 62 matrices.)
+    const int nt = (n + GT - 1) / GT;
     // (... and stops at N = 8192: the kernel FITS up to N = 16384 -- forced sequence 4, tests -- but was only ever measured to
     // win up to 65 panels; at N = 16384 the tasks are milliseconds long and the launch sequences keep the chip as full:
     // profiles/r06_a_dataflow_n16384.txt)

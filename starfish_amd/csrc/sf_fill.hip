@@ -44,6 +44,24 @@ __device__ __forceinline__ double sf_local_metric(double w, double mu) {
     return SF_C_KMS / mu * fabs(w - mu);  // kernels.py:69
 }
 
+// The tile bodies evaluate the two element formulas for 16 entries per lane: inlined (fp64 cos with its argument reduction, exp:
+// ~1 KB of code each) the structured tile body is 66-70 KB of straight-line code per tile -- more than the 64 KB instruction
+// cache of a CU pair holds.  As real calls (-DSF_FILL_CALL_ELEMS) the kernels are 15 KB, 143 instead of 163 VGPRs, same bits
+// -- and no faster where it counts (round 6, same box: dense fill of cfg 2 3.39 -> 3.43 ms, N = 3000 with ld = N 2.40 ->
+// 2.27, ld = 3008 2.15 -> 2.09, the likelihood's tile-list fill 0.495 both: profiles/r06_d_fill_called_elements_ab.txt):
+// sequential code streams through the instruction prefetch, the kernel is bound by the latency of its fp64 chains.  Inlined.
+#ifndef SF_FILL_CALL_ELEMS
+#define SF_ELEM_CALL __forceinline__
+#else
+#define SF_ELEM_CALL __attribute__((noinline))
+#endif
+__device__ SF_ELEM_CALL double sf_matern_elem_t(double w_row, double w_col, double amp, double ls, double r0) {
+    return sf_matern_elem(w_row, w_col, amp, ls, r0);
+}
+__device__ SF_ELEM_CALL double sf_local_elem_t(double d_row, double d_col, double amp, double sigma, double r0) {
+    return sf_local_elem(d_row, d_col, amp, sigma, r0);
+}
+
 #define SF_MAX_LOCAL 32
 
 // Which 128 x 128 tiles of the lower triangle carry anything besides the rank-m term (diagonal
@@ -194,7 +212,7 @@ __device__ __forceinline__ void sf_tile_finish(const sf_fill_args& a, int b, int
                 } else if (do_glob) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (col0 + r < a.n) v[r] = v[r] + sf_matern_elem(w_row, w_col[r], g_amp, g_ls, g_r0);
+                        if (col0 + r < a.n) v[r] = v[r] + sf_matern_elem_t(w_row, w_col[r], g_amp, g_ls, g_r0);
                 }
                 if (lmask) {
                     double loc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -206,7 +224,7 @@ __device__ __forceinline__ void sf_tile_finish(const sf_fill_args& a, int b, int
                         const double d_row = sf_local_metric(w_row, mu);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            loc[r] = loc[r] + sf_local_elem(d_row, sf_local_metric(w_col[r], mu), amp, sig, 4 * sig);
+                            loc[r] = loc[r] + sf_local_elem_t(d_row, sf_local_metric(w_col[r], mu), amp, sig, 4 * sig);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)

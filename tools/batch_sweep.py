@@ -19,7 +19,7 @@ for cfg, batches in plans:
                             "--warmup", "2", "--cpu-sample", "0", "--no-structured", "--no-extra-legs"], capture_output=True, text=True)
         d = json.loads(r.stdout.strip().splitlines()[-1])
         rows.append(dict(batch=B, ranks_equivalent=batches[0] // B, evals_per_s=d["value"], ms_per_step=d["ms_per_step"],
-                         ms_per_eval=d["ms_per_step"] / B, panel_frac_of_peak=d["roofline"]["frac"]))
+                         ms_per_eval=d["ms_per_step"] / B, panel_frac_of_peak=d["roofline"].get("panel_frac", d["roofline"]["frac"]), whole_path_frac=d["roofline"]["frac"]))
     base = rows[0]["ms_per_eval"]
     for r_ in rows:
         r_["per_eval_efficiency_vs_full_batch"] = base / r_["ms_per_eval"]
