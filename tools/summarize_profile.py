@@ -57,13 +57,15 @@ trace_f = find("stats/**/*kernel_trace.csv")
 union, union_rows = None, []
 if trace_f:
     tr = sorted(csv.DictReader(open(trace_f)), key=lambda r: int(r["Start_Timestamp"]))
-    nsteps = max(1, sum(1 for r in tr if r["Kernel_Name"].startswith("k_finish")))
+    nfinish = max(1, sum(1 for r in tr if r["Kernel_Name"].startswith("k_finish")))
     iv = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in tr if any(p in r["Kernel_Name"] for p in PANEL)]
     under = bench_line("bench_under_rocprof.json")
     roof = under.get("roofline") or {}
+    # steps of the traced run: what its own line says (warm-up included); a multi-order step has one k_finish per CHUNK
+    nsteps = int(under["steps"] + under["warmup"]) if "steps" in under and "warmup" in under else nfinish
     if iv:
         uni = interval_union(iv)
-        union = {"k_finish_calls": nsteps, "launches": len(iv), "union_ms_total": uni / 1e6,
+        union = {"k_finish_calls": nfinish, "steps": nsteps, "launches": len(iv), "union_ms_total": uni / 1e6,
                  "sum_ms_total": sum(b - a for a, b in iv) / 1e6}
         # algorithmic flops of the panel launches of ONE step, as the library counts them (bench line of the same run)
         gf = None
