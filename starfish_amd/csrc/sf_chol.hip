@@ -2235,8 +2235,10 @@ __device__ __forceinline__ void sf_panelw_body(const sf_panelw_args& g, const in
     }
 
     // ---------------------------------------------------------------- 2: triangular solves through LDS
-    double* Ach = smw;                          // [128][CLD] chunk of the A operand (accumulator -> operand layout)
-    double* Bs = smw + GT * CLD;                // [2][128][GLD] 16-column blocks of W  /  [128][CLD] chunk of L21
+    // (round 6: the chunk buffers alternate -- a chunk is dumped while the previous one is still being read, so the barrier
+    // that used to stand in front of every dump is gone: 12 of the epilogue's ~36 workgroup-wide barriers)
+    double* Ach0 = smw;                         // [2][128][CLD] chunks of the A operand (accumulator -> operand layout)
+    double* Bs = smw + 2 * GT * CLD;            // [2][128][GLD] 16-column blocks of W  /  [2][128][CLD] chunks of L21
     const int lr = tid >> 3, lc = (tid & 7) * 2;  // staging: 128 rows x 8 threads
     // L = T W on the blocks NB, NB + 1 of every wave (NB = 0: panel k, NB = 2: panel k + 1), K blocks in descending order
     // (rw: the K block 7 of W, requested by the caller ahead of the phase that precedes the solve: every global round trip of
@@ -2250,8 +2252,10 @@ __device__ __forceinline__ void sf_panelw_body(const sf_panelw_args& g, const in
 #pragma unroll
         for (int sbi = 0; sbi < 8; ++sbi) {
             const int sb = 7 - sbi;
+            double* Ach = Ach0 + ((sb >> 1) & 1) * (GT * CLD);  // (chunk sb / 2: its buffer was last read two chunks = four barriers ago)
+            // (the phase before the second solve -- step 2b -- reads the same buffers: one barrier in front of its first dump)
+            if (sb == 7 && NB != 0) __syncthreads();
             if (sb & 1) {  // first block of chunk sb / 2: its owner waves hand their T blocks over
-                __syncthreads();
                 if (wn == (sb >> 1)) {
 #pragma unroll
                     for (int nn = 0; nn < 2; ++nn)
@@ -2303,7 +2307,6 @@ __device__ __forceinline__ void sf_panelw_body(const sf_panelw_args& g, const in
     // 2b: T2 -= L1 L21^T, 32 columns of L1 at a time (chunk q = the blocks of the waves wn == q)
     {
         const double* L21 = Cb + (int64_t)(k0 + GT + lr) * g.lda + k0 + (tid & 7) * 4;
-        double* Bc = Bs;  // [128][CLD]
         auto l21 = [&](int q, double2& l0, double2& l1) {
             const bool real = (tid & 7) * 4 + q * 32 >= cfp;
             l0 = real ? *(const double2*)(L21 + q * 32) : make_double2(0.0, 0.0);
@@ -2314,7 +2317,9 @@ __device__ __forceinline__ void sf_panelw_body(const sf_panelw_args& g, const in
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q + 1 < 4) l21(q + 1, n0, n1);  // (the next chunk is in flight under this chunk's MFMAs)
-            __syncthreads();  // previous chunk consumed
+            double* Ach = Ach0 + (q & 1) * (GT * CLD);
+            double* Bc = Bs + (q & 1) * (GT * CLD);  // [128][CLD]
+            if (q == 0) __syncthreads();  // the first solve's last reads of the buffers are done
             if (wn == q) {
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn)
