@@ -348,3 +348,41 @@ def test_header_documents_no_environment_switch_and_the_persistent_kernel_status
     blob = open(os.path.join(ROOT, "starfish_amd", "libstarfish_amd.so"), "rb").read()
     for name in (b"SF_DF_STALL_MS", b"SF_DF_MISS_CLAIMS", b"SF_DF_TIMEOUT_S", b"SF_WIDE_HEAD", b"getenv"):
         assert name not in blob, name
+
+
+def test_multiplan_collect_raises_when_the_internal_status_survives_the_retry(monkeypatch):
+    """Advisor, round 5: MultiPlan.collect re-ran an aborted call once and then handed a SECOND -5 back as an ordinary
+    per-unit status.  Host logic only (no device): collect_multi is replaced by a fake that keeps returning -5."""
+    from starfish_amd import _device as D
+
+    class FakeLib:
+        def __init__(self):
+            self.switched = []
+
+        def sf_persistent_potrf_status(self, buf):
+            for i, v in enumerate((1, 2, 400, 512, 3_000_000, 77, 1, 1)):
+                buf[i] = v
+            return 0
+
+        def sf_persistent_potrf(self, v):
+            self.switched.append(v)
+            return 1
+
+    plan = D.MultiPlan.__new__(D.MultiPlan)
+    plan.lib, plan.quad, plan.info, plan.sizes = FakeLib(), None, None, [2]
+    calls = []
+    plan.enqueue = lambda: calls.append("enqueue")
+    bad = [dict(lnl=np.full(2, -np.inf), logdet=np.zeros(2), sqmah=np.zeros(2), log_scale=np.zeros(2),
+                info=np.full(2, D.INFO_INTERNAL, dtype=np.int32))]
+    monkeypatch.setattr(D, "collect_multi", lambda quad, info, sizes: bad)
+    with pytest.warns(RuntimeWarning, match="no task of the launch completed for 25 ms; only 400 of its 512 workgroups had started"):
+        with pytest.raises(RuntimeError, match="internal error"):
+            plan.collect()
+    assert calls == ["enqueue"] and plan.lib.switched == [0]
+    # ... and a retry that succeeds is returned
+    good = [dict(bad[0], info=np.zeros(2, dtype=np.int32), lnl=np.ones(2))]
+    seq = iter([bad, good])
+    monkeypatch.setattr(D, "collect_multi", lambda quad, info, sizes: next(seq))
+    with pytest.warns(RuntimeWarning, match="disabled for this whole process"):
+        out = plan.collect()
+    assert (out[0]["info"] == 0).all()
